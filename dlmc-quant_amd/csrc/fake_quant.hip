@@ -1,0 +1,429 @@
+// Fake-quantize kernels for gfx950 (MI355X): clamp-round-dequant in ONE pass over HBM.
+//
+// Roofline: HBM.  Per element 4 B read + 4 B written (+1 B int8 codes, +0.5 B packed int4) against
+// ~25 VALU instructions (one IEEE fp32 division dominates): arithmetic intensity << machine balance,
+// so everything here is about the memory system:
+//   * 128-bit (dwordx4) loads and stores, lane i at base + 16*i: one 1 KiB request per wave-instruction;
+//   * U independent loads issued before the first use, so each wave keeps U KiB in flight;
+//   * per-channel (scale, offset) pairs staged ONCE per block into LDS - only the rows the block's
+//     chunk touches - and read back with a broadcast ds_read; the channel of an element comes from an
+//     exact multiply-shift division, never from a per-element integer divide or a transposed copy;
+//   * streaming (non-temporal) stores: the output is not re-read by this kernel.
+// Bit-exactness: true IEEE division, rintf (half-to-even), the reference's own operation order and its
+// STE identities (ste_round / ste_scale), no FMA contraction (-ffp-contract=off), fp32 denormals kept.
+#include "dlmcq_internal.h"
+
+namespace dlmcq {
+
+// Per-channel constants of one form, derived from the stored (scale, offset) exactly as the
+// reference derives them, once per float4 (or once per thread when the whole tensor shares them).
+template <int FORM>
+struct ChanConst {
+  float dv;   // divisor
+  float ml;   // multiplier of the dequant
+  float of;   // offset / zero point
+  float up;   // ROOTQ_ACT: upper clip
+  __device__ __forceinline__ ChanConst(float s, float o, float g, float lo, float hi) {
+    of = o;
+    up = 0.0f;
+    if (FORM == DLMCQ_FORM_EMULATE) {
+      dv = s + 1e-7f;
+      ml = s;
+    } else if (FORM == DLMCQ_FORM_QBASE) {
+      dv = ste_scale(s, g);
+      ml = dv;
+    } else {
+      dv = s;
+      ml = s;
+      if (FORM == DLMCQ_FORM_ROOTQ_ACT) up = s * (hi - lo);
+    }
+  }
+};
+
+// One element: returns the code q (fp32, integral or NaN) and the fake-quantised value y.
+template <int FORM>
+__device__ __forceinline__ void fq_one(float x, const ChanConst<FORM>& c, float lo, float hi, float& q,
+                                       float& y) {
+  if (FORM == DLMCQ_FORM_EMULATE) {
+    q = clamp_nan(__builtin_rintf((x - c.of) / c.dv), lo, hi);
+    y = q * c.ml + c.of;
+  } else if (FORM == DLMCQ_FORM_QBASE) {
+    q = ste_round(clamp_nan((x - c.of) / c.dv, lo, hi));
+    y = q * c.ml + c.of;
+  } else if (FORM == DLMCQ_FORM_ZEROPOINT) {
+    q = clamp_nan(ste_round(x / c.dv) + c.of, lo, hi);
+    y = (q - c.of) * c.ml;
+  } else if (FORM == DLMCQ_FORM_SYMMETRIC) {
+    q = clamp_nan(ste_round(x / c.dv), lo, hi);
+    y = q * c.ml;
+  } else {  // DLMCQ_FORM_ROOTQ_ACT
+    float t = x + relu_nan(0.0f - x);
+    t = t - relu_nan(t - c.up);
+    q = ste_round(t / c.dv);
+    y = q * c.ml;
+  }
+}
+
+// Four elements sharing one channel.
+template <int FORM>
+__device__ __forceinline__ void fq4(const f32x4& v, const ChanConst<FORM>& c, float lo, float hi, f32x4& q, f32x4& y) {
+  float q0, q1, q2, q3, y0, y1, y2, y3;
+  fq_one<FORM>(v.x, c, lo, hi, q0, y0);
+  fq_one<FORM>(v.y, c, lo, hi, q1, y1);
+  fq_one<FORM>(v.z, c, lo, hi, q2, y2);
+  fq_one<FORM>(v.w, c, lo, hi, q3, y3);
+  q = f32x4{q0, q1, q2, q3};
+  y = f32x4{y0, y1, y2, y3};
+}
+
+struct FqOut {
+  float* y;
+  uint8_t* codes;
+  int y_kind;
+  int codes_kind;
+};
+
+// Store one float4 worth of results at global element index `gidx` (multiple of 4).
+__device__ __forceinline__ void store4(const FqOut& o, int64_t gidx, const f32x4& q, const f32x4& y) {
+  if (o.y) {
+    f32x4 v = o.y_kind == DLMCQ_Y_CODES ? q : y;
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o.y + gidx));
+  }
+  if (o.codes_kind == DLMCQ_CODES_I8) {
+    uint32_t w = (uint32_t)(code_of(q.x) & 0xff) | ((uint32_t)(code_of(q.y) & 0xff) << 8) |
+                 ((uint32_t)(code_of(q.z) & 0xff) << 16) | ((uint32_t)(code_of(q.w) & 0xff) << 24);
+    __builtin_nontemporal_store(w, reinterpret_cast<uint32_t*>(o.codes + gidx));
+  } else if (o.codes_kind == DLMCQ_CODES_P4) {
+    uint16_t w = (uint16_t)((code_of(q.x) & 0xf) | ((code_of(q.y) & 0xf) << 4) | ((code_of(q.z) & 0xf) << 8) |
+                            ((code_of(q.w) & 0xf) << 12));
+    __builtin_nontemporal_store(w, reinterpret_cast<uint16_t*>(o.codes + (gidx >> 1)));
+  }
+}
+
+// ------------------------------------------------------------------ per-tensor, 128-bit path
+// Grid-stride over chunks of 256*U float4.  n4 = numel/4; the 0-3 tail elements are finished by
+// the first lanes of block 0.
+template <int FORM, int U>
+__global__ __launch_bounds__(DLMCQ_BLOCK) void fq_tensor_kernel(const float* x, FqOut out,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ offset, int64_t n,
+                                                               float lo, float hi, float g) {
+  const ChanConst<FORM> c(scale[0], offset ? offset[0] : 0.0f, g, lo, hi);
+  const int64_t n4 = n >> 2;
+  const int64_t nchunks = (n4 + DLMCQ_BLOCK * U - 1) / (DLMCQ_BLOCK * U);
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);  // no __restrict__: y may alias x
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int64_t i0 = chunk * (DLMCQ_BLOCK * U) + threadIdx.x;
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * DLMCQ_BLOCK;
+      if (i < n4) v[u] = __builtin_nontemporal_load(x4 + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * DLMCQ_BLOCK;
+      if (i < n4) {
+        f32x4 q, y;
+        fq4<FORM>(v[u], c, lo, hi, q, y);
+        store4(out, i << 2, q, y);
+      }
+    }
+  }
+  // tail: fewer than 4 elements, one per lane of block 0 (static indexing only: no scratch)
+  const int r = (int)(n & 3);
+  if (blockIdx.x == 0 && threadIdx.x < r) {
+    const int64_t b = n4 << 2;
+    float q, y;
+    fq_one<FORM>(x[b + threadIdx.x], c, lo, hi, q, y);
+    if (out.y) out.y[b + threadIdx.x] = out.y_kind == DLMCQ_Y_CODES ? q : y;
+    if (out.codes_kind == DLMCQ_CODES_I8) out.codes[b + threadIdx.x] = (uint8_t)(code_of(q) & 0xff);
+    if (out.codes_kind == DLMCQ_CODES_P4) {
+      // lanes 0/1 and 2 hold the nibbles of bytes 0 and 1: combine through a wave shuffle
+      const int mine = code_of(q) & 0xf;
+      const int next = __shfl_down(mine, 1, DLMCQ_WAVE);
+      if ((threadIdx.x & 1) == 0)
+        out.codes[(b + threadIdx.x) >> 1] = (uint8_t)(mine | ((threadIdx.x + 1 < r ? next : 0) << 4));
+    }
+  }
+}
+
+// ----------------------------------------------------------------- per-channel, 128-bit path
+// The tensor is (outer, channels, inner); a "slab" is one outer index = channels*inner contiguous
+// elements (< 2^31, multiple of 4).  Block b handles chunk (b % cps) of slab (b / cps); a chunk is
+// 256*U float4.  Only the (scale, offset) rows that chunk touches are staged into LDS.
+struct ChanGeom {
+  int64_t slab;      // channels * inner
+  uint32_t cps;      // chunks per slab
+  FastDiv inner;     // element-in-slab -> channel
+  FastDiv cpsdiv;    // block -> slab
+};
+
+template <int FORM, int U, bool ROW_UNIFORM>
+__global__ __launch_bounds__(DLMCQ_BLOCK) void fq_channel_kernel(const float* x, FqOut out,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ offset, ChanGeom gm,
+                                                                float lo, float hi, float g) {
+  extern __shared__ float2 tbl[];  // [rows touched by this chunk] {scale, offset}
+  constexpr uint32_t CH = DLMCQ_BLOCK * U * 4;  // elements per chunk
+  const uint32_t slab_i = fdiv(blockIdx.x, gm.cpsdiv);
+  const uint32_t cx = blockIdx.x - slab_i * gm.cps;
+  const uint32_t slab = (uint32_t)gm.slab;
+  const uint32_t e0 = cx * CH;
+  const uint32_t e_end = (e0 + CH < slab) ? e0 + CH : slab;
+  const uint32_t ch0 = fdiv(e0, gm.inner);
+  const uint32_t nrows = fdiv(e_end - 1, gm.inner) - ch0 + 1;
+  for (uint32_t t = threadIdx.x; t < nrows; t += DLMCQ_BLOCK)
+    tbl[t] = make_float2(scale[ch0 + t], offset ? offset[ch0 + t] : 0.0f);
+
+  const int64_t base = (int64_t)slab_i * gm.slab;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x + base);
+  f32x4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t e = e0 + (u * DLMCQ_BLOCK + threadIdx.x) * 4;
+    if (e < slab) v[u] = __builtin_nontemporal_load(x4 + (e >> 2));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t e = e0 + (u * DLMCQ_BLOCK + threadIdx.x) * 4;
+    if (e < slab) {
+      f32x4 q, y;
+      if (ROW_UNIFORM) {  // inner % 4 == 0: the four lanes of a float4 share one channel
+        const float2 so = tbl[fdiv(e, gm.inner) - ch0];
+        const ChanConst<FORM> c(so.x, so.y, g, lo, hi);
+        fq4<FORM>(v[u], c, lo, hi, q, y);
+      } else {
+        const uint32_t r0 = fdiv(e, gm.inner);
+        const uint32_t r3 = fdiv(e + 3, gm.inner);
+        if (r0 == r3) {
+          const float2 so = tbl[r0 - ch0];
+          const ChanConst<FORM> c(so.x, so.y, g, lo, hi);
+          fq4<FORM>(v[u], c, lo, hi, q, y);
+        } else {
+          float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          float qv[4], yv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float2 so = tbl[fdiv(e + j, gm.inner) - ch0];
+            const ChanConst<FORM> c(so.x, so.y, g, lo, hi);
+            fq_one<FORM>(xv[j], c, lo, hi, qv[j], yv[j]);
+          }
+          q = f32x4{qv[0], qv[1], qv[2], qv[3]};
+          y = f32x4{yv[0], yv[1], yv[2], yv[3]};
+        }
+      }
+      store4(out, base + e, q, y);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- generic fallback
+// Any alignment, any shape: one element PAIR per thread (so packed-int4 bytes have one writer),
+// 64-bit index arithmetic with real divisions.  Correct everywhere, fast nowhere; it only runs for
+// unaligned views and shapes whose slab is not a multiple of 4 elements.
+template <int FORM>
+__global__ __launch_bounds__(DLMCQ_BLOCK) void fq_generic_kernel(const float* x, FqOut out,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ offset, int64_t n,
+                                                                int64_t channels, int64_t inner, float lo,
+                                                                float hi, float g) {
+  const int64_t npairs = (n + 1) >> 1;
+  for (int64_t p = (int64_t)blockIdx.x * DLMCQ_BLOCK + threadIdx.x; p < npairs;
+       p += (int64_t)gridDim.x * DLMCQ_BLOCK) {
+    int codes[2] = {0, 0};
+    for (int j = 0; j < 2; ++j) {
+      const int64_t i = 2 * p + j;
+      if (i >= n) break;
+      const int64_t ch = channels == 1 ? 0 : (i / inner) % channels;
+      const ChanConst<FORM> c(scale[ch], offset ? offset[ch] : 0.0f, g, lo, hi);
+      float q, y;
+      fq_one<FORM>(x[i], c, lo, hi, q, y);
+      if (out.y) out.y[i] = out.y_kind == DLMCQ_Y_CODES ? q : y;
+      codes[j] = code_of(q);
+      if (out.codes_kind == DLMCQ_CODES_I8) out.codes[i] = (uint8_t)(codes[j] & 0xff);
+    }
+    if (out.codes_kind == DLMCQ_CODES_P4) out.codes[p] = (uint8_t)((codes[0] & 0xf) | ((codes[1] & 0xf) << 4));
+  }
+}
+
+// ----------------------------------------------------------------------------- dequant kernels
+template <int FORM>
+__device__ __forceinline__ float dq_one(float q, const ChanConst<FORM>& c) {
+  if (FORM == DLMCQ_FORM_EMULATE || FORM == DLMCQ_FORM_QBASE) return q * c.ml + c.of;
+  if (FORM == DLMCQ_FORM_ZEROPOINT) return (q - c.of) * c.ml;
+  return q * c.ml;
+}
+
+// Codes (int8/uint8/packed nibbles) or fp32 codes -> fp32.  SRC: 0 = fp32, 1 = I8, 2 = P4.
+// One element pair per thread keeps the three sources uniform; this is the deployment-time unpack,
+// 1-1.5 B read + 4 B written per element.
+template <int FORM, int SRC>
+__global__ __launch_bounds__(DLMCQ_BLOCK) void dequant_kernel(const void* __restrict__ src, float* __restrict__ y,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ offset, int64_t n,
+                                                             int64_t channels, int64_t inner, int is_signed,
+                                                             float g) {
+  const int64_t npairs = (n + 1) >> 1;
+  for (int64_t p = (int64_t)blockIdx.x * DLMCQ_BLOCK + threadIdx.x; p < npairs;
+       p += (int64_t)gridDim.x * DLMCQ_BLOCK) {
+    float q[2];
+    if (SRC == 0) {
+      q[0] = reinterpret_cast<const float*>(src)[2 * p];
+      q[1] = (2 * p + 1 < n) ? reinterpret_cast<const float*>(src)[2 * p + 1] : 0.0f;
+    } else if (SRC == 1) {
+      const uint8_t* b = reinterpret_cast<const uint8_t*>(src);
+      const uint8_t b0 = b[2 * p], b1 = (2 * p + 1 < n) ? b[2 * p + 1] : 0;
+      q[0] = is_signed ? (float)(int8_t)b0 : (float)b0;
+      q[1] = is_signed ? (float)(int8_t)b1 : (float)b1;
+    } else {
+      const uint8_t b = reinterpret_cast<const uint8_t*>(src)[p];
+      const int l = b & 0xf, h = b >> 4;
+      q[0] = (float)(is_signed ? ((l ^ 8) - 8) : l);
+      q[1] = (float)(is_signed ? ((h ^ 8) - 8) : h);
+    }
+    for (int j = 0; j < 2; ++j) {
+      const int64_t i = 2 * p + j;
+      if (i >= n) break;
+      const int64_t ch = channels == 1 ? 0 : (i / inner) % channels;
+      const ChanConst<FORM> c(scale[ch], offset ? offset[ch] : 0.0f, g, 0.0f, 0.0f);
+      y[i] = dq_one<FORM>(q[j], c);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- host side
+static int blocks_for(int64_t work_items, int per_block, int max_blocks) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+constexpr int FQ_U = 4;                       // float4 per thread per chunk: 4 KiB in flight per wave
+constexpr int FQ_MAX_BLOCKS = DLMCQ_CUS * 16; // per-tensor grid cap (grid-stride beyond it)
+
+template <int FORM>
+static int launch_fq(const float* x, const FqOut& out, const float* scale, const float* offset, int64_t outer,
+                     int64_t channels, int64_t inner, float lo, float hi, float g, hipStream_t st) {
+  const int64_t n = outer * channels * inner;
+  const bool vec = aligned16(x) && (!out.y || aligned16(out.y)) && (!out.codes || aligned4(out.codes));
+  if (channels == 1 && vec) {
+    const int64_t n4 = n >> 2;
+    const int grid = blocks_for(n4, DLMCQ_BLOCK * FQ_U, FQ_MAX_BLOCKS);
+    hipLaunchKernelGGL((fq_tensor_kernel<FORM, FQ_U>), dim3(grid), dim3(DLMCQ_BLOCK), 0, st, x, out, scale, offset,
+                       n, lo, hi, g);
+    return launch_status();
+  }
+  const int64_t slab = channels * inner;
+  if (channels > 1 && vec && (slab % 4 == 0) && slab < (1ll << 31)) {
+    constexpr int64_t CH = (int64_t)DLMCQ_BLOCK * FQ_U * 4;
+    ChanGeom gm;
+    gm.slab = slab;
+    gm.cps = (uint32_t)((slab + CH - 1) / CH);
+    const int64_t blocks = (int64_t)gm.cps * outer;
+    if (blocks >= (1ll << 31)) return DLMCQ_ERANGE;
+    gm.inner = make_fastdiv((uint32_t)inner);
+    gm.cpsdiv = make_fastdiv(gm.cps);
+    // rows a chunk can touch: CH/inner + 2, never more than CH (inner >= 1) or the channel count
+    int64_t rows = CH / inner + 2;
+    if (rows > CH) rows = CH;
+    if (rows > channels) rows = channels;
+    const size_t lds = (size_t)rows * sizeof(float2);
+    if (inner % 4 == 0)
+      hipLaunchKernelGGL((fq_channel_kernel<FORM, FQ_U, true>), dim3((uint32_t)blocks), dim3(DLMCQ_BLOCK), lds, st, x,
+                         out, scale, offset, gm, lo, hi, g);
+    else
+      hipLaunchKernelGGL((fq_channel_kernel<FORM, FQ_U, false>), dim3((uint32_t)blocks), dim3(DLMCQ_BLOCK), lds, st,
+                         x, out, scale, offset, gm, lo, hi, g);
+    return launch_status();
+  }
+  if (channels > 1 && slab >= (1ll << 31) && !(slab % 4)) {
+    // still correct through the generic kernel, but say so: this is far off the fast path
+  }
+  const int grid = blocks_for((n + 1) / 2, DLMCQ_BLOCK, DLMCQ_CUS * 32);
+  hipLaunchKernelGGL((fq_generic_kernel<FORM>), dim3(grid), dim3(DLMCQ_BLOCK), 0, st, x, out, scale, offset, n,
+                     channels, inner, lo, hi, g);
+  return launch_status();
+}
+
+template <int SRC>
+static int launch_dq(const void* src, float* y, const float* scale, const float* offset, int64_t n, int64_t channels,
+                     int64_t inner, int form, int is_signed, float g, hipStream_t st) {
+  const int grid = blocks_for((n + 1) / 2, DLMCQ_BLOCK, DLMCQ_CUS * 32);
+#define DLMCQ_DQ(F)                                                                                               \
+  hipLaunchKernelGGL((dequant_kernel<F, SRC>), dim3(grid), dim3(DLMCQ_BLOCK), 0, st, src, y, scale, offset, n, \
+                     channels, inner, is_signed, g)
+  switch (form) {
+    case DLMCQ_FORM_EMULATE: DLMCQ_DQ(DLMCQ_FORM_EMULATE); break;
+    case DLMCQ_FORM_QBASE: DLMCQ_DQ(DLMCQ_FORM_QBASE); break;
+    case DLMCQ_FORM_ZEROPOINT: DLMCQ_DQ(DLMCQ_FORM_ZEROPOINT); break;
+    case DLMCQ_FORM_SYMMETRIC: DLMCQ_DQ(DLMCQ_FORM_SYMMETRIC); break;
+    case DLMCQ_FORM_ROOTQ_ACT: DLMCQ_DQ(DLMCQ_FORM_ROOTQ_ACT); break;
+    default: return DLMCQ_EINVAL;
+  }
+#undef DLMCQ_DQ
+  return launch_status();
+}
+
+}  // namespace dlmcq
+
+using namespace dlmcq;
+
+extern "C" int dlmcq_fake_quant_f32(const float* x, float* y, void* codes, const float* scale, const float* offset,
+                                    int64_t outer, int64_t channels, int64_t inner, int32_t lo, int32_t hi,
+                                    int32_t form, int32_t y_kind, int32_t codes_kind, float ste_g,
+                                    dlmcq_stream_t stream) {
+  if (outer < 0 || channels < 1 || inner < 0) return DLMCQ_EINVAL;
+  if (lo > hi) return DLMCQ_EINVAL;
+  if (form < 0 || form >= DLMCQ_FORM_COUNT) return DLMCQ_EINVAL;
+  if (y_kind != DLMCQ_Y_DEQUANT && y_kind != DLMCQ_Y_CODES) return DLMCQ_EINVAL;
+  if (codes_kind < DLMCQ_CODES_NONE || codes_kind > DLMCQ_CODES_P4) return DLMCQ_EINVAL;
+  if ((codes_kind != DLMCQ_CODES_NONE) != (codes != nullptr)) return DLMCQ_EINVAL;
+  if (codes_kind == DLMCQ_CODES_I8 && (lo < -128 || hi > 255 || (lo < 0 && hi > 127))) return DLMCQ_EINVAL;
+  if (codes_kind == DLMCQ_CODES_P4 && (lo < -8 || hi > 15 || (lo < 0 && hi > 7))) return DLMCQ_EINVAL;
+  const int64_t n = outer * channels * inner;
+  if (n == 0) return DLMCQ_OK;  // empty tensor: nothing to do, pointers may be anything
+  if (!x || !scale || (!y && !codes)) return DLMCQ_EINVAL;
+  FqOut out{y, reinterpret_cast<uint8_t*>(codes), y_kind, codes_kind};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float flo = (float)lo, fhi = (float)hi;
+  switch (form) {
+    case DLMCQ_FORM_EMULATE:
+      return launch_fq<DLMCQ_FORM_EMULATE>(x, out, scale, offset, outer, channels, inner, flo, fhi, ste_g, st);
+    case DLMCQ_FORM_QBASE:
+      return launch_fq<DLMCQ_FORM_QBASE>(x, out, scale, offset, outer, channels, inner, flo, fhi, ste_g, st);
+    case DLMCQ_FORM_ZEROPOINT:
+      return launch_fq<DLMCQ_FORM_ZEROPOINT>(x, out, scale, offset, outer, channels, inner, flo, fhi, ste_g, st);
+    case DLMCQ_FORM_SYMMETRIC:
+      return launch_fq<DLMCQ_FORM_SYMMETRIC>(x, out, scale, offset, outer, channels, inner, flo, fhi, ste_g, st);
+    default:
+      return launch_fq<DLMCQ_FORM_ROOTQ_ACT>(x, out, scale, offset, outer, channels, inner, flo, fhi, ste_g, st);
+  }
+}
+
+extern "C" int dlmcq_dequant_codes_f32(const void* codes, float* y, const float* scale, const float* offset,
+                                       int64_t outer, int64_t channels, int64_t inner, int32_t form,
+                                       int32_t codes_kind, int32_t is_signed, float ste_g, dlmcq_stream_t stream) {
+  if (outer < 0 || channels < 1 || inner < 0) return DLMCQ_EINVAL;
+  if (form < 0 || form >= DLMCQ_FORM_COUNT) return DLMCQ_EINVAL;
+  if (codes_kind != DLMCQ_CODES_I8 && codes_kind != DLMCQ_CODES_P4) return DLMCQ_EINVAL;
+  const int64_t n = outer * channels * inner;
+  if (n == 0) return DLMCQ_OK;
+  if (!codes || !y || !scale) return DLMCQ_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (codes_kind == DLMCQ_CODES_I8)
+    return launch_dq<1>(codes, y, scale, offset, n, channels, inner, form, is_signed, ste_g, st);
+  return launch_dq<2>(codes, y, scale, offset, n, channels, inner, form, is_signed, ste_g, st);
+}
+
+extern "C" int dlmcq_dequant_f32(const float* q, float* y, const float* scale, const float* offset, int64_t outer,
+                                 int64_t channels, int64_t inner, dlmcq_stream_t stream) {
+  if (outer < 0 || channels < 1 || inner < 0) return DLMCQ_EINVAL;
+  const int64_t n = outer * channels * inner;
+  if (n == 0) return DLMCQ_OK;
+  if (!q || !y || !scale) return DLMCQ_EINVAL;
+  return launch_dq<0>(q, y, scale, offset, n, channels, inner, DLMCQ_FORM_EMULATE, 0, 0.0f,
+                      reinterpret_cast<hipStream_t>(stream));
+}

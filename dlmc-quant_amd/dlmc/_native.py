@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI in include/dlmcq.h (libdlmcq.so, built by csrc/Makefile).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the import fails,
+and every call on a non-GPU tensor raises.  The product path is the HIP path or nothing.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdlmcq.so")
+
+# enums of include/dlmcq.h
+FORM_EMULATE, FORM_QBASE, FORM_ZEROPOINT, FORM_SYMMETRIC, FORM_ROOTQ_ACT = range(5)
+Y_DEQUANT, Y_CODES = 0, 1
+CODES_NONE, CODES_I8, CODES_P4 = 0, 1, 2
+MINMAX_ABSMAX, MINMAX_MINMAX, MINMAX_NEGMIN = 0, 1, 2
+
+_p, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
+
+# symbol -> (restype, argtypes); must list every function include/dlmcq.h declares
+SIGNATURES = {
+    "dlmcq_version": (ctypes.c_int, []),
+    "dlmcq_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "dlmcq_fake_quant_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _p]),
+    "dlmcq_dequant_codes_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _p]),
+    "dlmcq_dequant_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "dlmcq_minmax_scratch_bytes": (_sz, [_i64, _i64, _i64]),
+    "dlmcq_minmax_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i32, _p, _sz, _p]),
+    "dlmcq_qparams_from_minmax": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f32, _p]),
+    "dlmcq_observe_qparams_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _p, _sz, _p]),
+    "dlmcq_pack_int4": (ctypes.c_int, [_p, _p, _i64, _p]),
+    "dlmcq_unpack_int4": (ctypes.c_int, [_p, _p, _i64, _i32, _p]),
+    "dlmcq_fq_bwd_scratch_bytes": (_sz, [_i64, _i64, _i64]),
+    "dlmcq_fake_quant_bwd_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _f32, _p, _sz, _p]),
+    "dlmcq_rootq_weight_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C dlmc-quant_amd/csrc` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback.")
+    # torch ships its own libamdhip64 (soname libamdhip64.so.7); load it first so that libdlmcq's
+    # DT_NEEDED resolves to the SAME runtime instance torch uses (pointers and streams are shared).
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tlib):
+        ctypes.CDLL(tlib, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+class DlmcqError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise DlmcqError(f"{lib.dlmcq_strerror(rc).decode()} (code {rc})")
+
+
+def stream_ptr():
+    """The hipStream_t torch is currently launching on (kernels are enqueued there, asynchronously)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DlmcqError(
+                "dlmc (MI355X build) runs on the GPU only: got a tensor on "
+                f"'{t.device}'.  There is no CPU fallback in this package.")

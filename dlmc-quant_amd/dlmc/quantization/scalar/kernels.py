@@ -1,0 +1,247 @@
+"""torch-tensor front end of the HIP kernels (include/dlmcq.h).
+
+Everything here is plumbing: shape bookkeeping, output allocation and the current-stream handle.
+The arithmetic happens in libdlmcq.so; tensors that are not on the GPU are refused (no fallback).
+"""
+import math
+
+import torch
+
+from ... import _native as N
+from ..._native import (CODES_I8, CODES_NONE, CODES_P4, FORM_EMULATE, FORM_QBASE, FORM_ROOTQ_ACT,
+                        FORM_SYMMETRIC, FORM_ZEROPOINT, MINMAX_ABSMAX, MINMAX_MINMAX, MINMAX_NEGMIN,
+                        Y_CODES, Y_DEQUANT)
+
+__all__ = ["fake_quant", "dequant_codes", "dequant", "minmax", "observe_qparams", "qparams_from_minmax",
+           "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
+           "PROFILE"]
+
+
+class _Profile:
+    """Optional HIP-event timing of the fake-quant launches (bench.py turns it on).  Events are
+    recorded on the stream the kernel is launched on, which is torch's current stream."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []  # (tag, algorithmic_bytes, start_event, stop_event)
+
+    def reset(self):
+        self.records = []
+
+    def launch(self, tag, nbytes, fn):
+        if not self.enabled:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.records.append((tag, nbytes, a, b))
+        return r
+
+
+PROFILE = _Profile()
+
+
+def _f32c(t, like):
+    """A contiguous fp32 tensor on `like`'s device (scale / offset operands)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        return torch.full((1,), float(t), dtype=torch.float32, device=like.device)
+    if t.dtype != torch.float32 or t.device != like.device:
+        t = t.to(device=like.device, dtype=torch.float32)
+    return t.contiguous()
+
+
+def geometry(x, scale, ch_axis=None):
+    """(outer, channels, inner) of contiguous `x` for a scale of shape [], [1] or [1,..,C,..,1]."""
+    n = x.numel()
+    if scale.numel() == 1:
+        return 1, 1, n
+    if ch_axis is None:
+        if scale.dim() != x.dim():
+            raise ValueError(f"per-channel scale {tuple(scale.shape)} must have the rank of x {tuple(x.shape)}")
+        axes = [i for i, s in enumerate(scale.shape) if s != 1]
+        if len(axes) != 1:
+            raise ValueError(f"scale {tuple(scale.shape)} is not a single-axis broadcast")
+        ch_axis = axes[0]
+    c = x.shape[ch_axis]
+    if scale.numel() != c:
+        raise ValueError(f"scale has {scale.numel()} entries, axis {ch_axis} of x has {c}")
+    outer = math.prod(x.shape[:ch_axis])
+    inner = math.prod(x.shape[ch_axis + 1:])
+    return outer, c, inner
+
+
+def channel_shape(x, ch_axis):
+    shape = [1] * x.dim()
+    shape[ch_axis] = x.shape[ch_axis]
+    return shape
+
+
+def fake_quant(x, scale, offset, lo, hi, form, g=0.0, y_kind=Y_DEQUANT, codes=None, want_y=True,
+               out=None, ch_axis=None):
+    """One-pass fake-quantisation.  Returns y, or (y, codes) when `codes` is "i8" / "p4"
+    (y is None when want_y is False)."""
+    N.require_gpu(x)
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        raise TypeError(f"fake_quant computes in fp32; got {x.dtype}")
+    scale, offset = _f32c(scale, x), _f32c(offset, x)
+    outer, ch, inner = geometry(x, scale, ch_axis)
+    if offset is not None and offset.numel() != scale.numel():
+        if offset.numel() == 1:
+            offset = offset.reshape(1).expand(scale.numel()).contiguous()
+        else:
+            raise ValueError("offset must have one entry per scale entry")
+    y = None
+    if want_y:
+        y = out if out is not None else torch.empty_like(x)
+        if not (y.is_contiguous() and y.dtype == torch.float32 and y.shape == x.shape):
+            raise ValueError("out must be a contiguous fp32 tensor of x's shape")
+    cbuf, ckind = None, CODES_NONE
+    n = x.numel()
+    if codes == "i8":
+        cbuf = torch.empty(x.shape, dtype=torch.int8 if lo < 0 else torch.uint8, device=x.device)
+        ckind = CODES_I8
+    elif codes == "p4":
+        cbuf = torch.empty((n + 1) // 2, dtype=torch.uint8, device=x.device)
+        ckind = CODES_P4
+    elif codes is not None:
+        raise ValueError("codes must be None, 'i8' or 'p4'")
+    nbytes = n * (4 + (4 if want_y else 0)) + (n if ckind == CODES_I8 else (n + 1) // 2 if ckind == CODES_P4 else 0)
+    PROFILE.launch(
+        "fq_channel" if ch > 1 else "fq_tensor", nbytes,
+        lambda: N.check(N.lib.dlmcq_fake_quant_f32(
+            N.ptr(x), N.ptr(y), N.ptr(cbuf), N.ptr(scale), N.ptr(offset), outer, ch, inner, int(lo), int(hi),
+            int(form), int(y_kind), ckind, float(g), N.stream_ptr())))
+    return y if cbuf is None else (y, cbuf)
+
+
+def dequant_codes(codes, shape, scale, offset, form, kind, signed, g=0.0, ch_axis=None):
+    """Integer codes (int8/uint8 tensor of `shape`, or packed nibbles) -> fp32."""
+    N.require_gpu(codes)
+    y = torch.empty(shape, dtype=torch.float32, device=codes.device)
+    scale, offset = _f32c(scale, y), _f32c(offset, y)
+    outer, ch, inner = geometry(y, scale, ch_axis)
+    ckind = CODES_I8 if kind == "i8" else CODES_P4
+    N.check(N.lib.dlmcq_dequant_codes_f32(N.ptr(codes.contiguous()), N.ptr(y), N.ptr(scale), N.ptr(offset), outer, ch,
+                                          inner, int(form), ckind, int(bool(signed)), float(g), N.stream_ptr()))
+    return y
+
+
+def dequant(q, scale, offset, ch_axis=None):
+    """Reference `dequantize` on fp32 codes: q*s + o."""
+    N.require_gpu(q)
+    q = q.contiguous()
+    y = torch.empty_like(q)
+    scale, offset = _f32c(scale, q), _f32c(offset, q)
+    outer, ch, inner = geometry(q, scale, ch_axis)
+    if offset is not None and offset.numel() != scale.numel():
+        offset = offset.reshape(1).expand(scale.numel()).contiguous()
+    N.check(N.lib.dlmcq_dequant_f32(N.ptr(q), N.ptr(y), N.ptr(scale), N.ptr(offset), outer, ch, inner, N.stream_ptr()))
+    return y
+
+
+def _obs_geometry(x, ch_axis):
+    if ch_axis is None:
+        return 1, 1, x.numel()
+    return math.prod(x.shape[:ch_axis]), x.shape[ch_axis], math.prod(x.shape[ch_axis + 1:])
+
+
+def _scratch(nbytes, device):
+    return torch.empty(max(int(nbytes), 4) // 4 + 1, dtype=torch.float32, device=device)
+
+
+def minmax(x, ch_axis=None, mode=MINMAX_MINMAX):
+    """(max, min) of x - per tensor (0-dim results) or per channel ([C] results) - in one read.
+    mode ABSMAX returns (max|x|, None); NEGMIN returns (max, -min)."""
+    N.require_gpu(x)
+    x = x.contiguous()
+    outer, ch, inner = _obs_geometry(x, ch_axis)
+    vmax = torch.empty(ch, dtype=torch.float32, device=x.device)
+    vmin = torch.empty(ch, dtype=torch.float32, device=x.device) if mode != MINMAX_ABSMAX else None
+    nb = N.lib.dlmcq_minmax_scratch_bytes(outer, ch, inner)
+    sc = _scratch(nb, x.device)
+    PROFILE.launch("observer", x.numel() * 4, lambda: N.check(N.lib.dlmcq_minmax_f32(
+        N.ptr(x), N.ptr(vmax), N.ptr(vmin), outer, ch, inner, int(mode), N.ptr(sc), sc.numel() * 4, N.stream_ptr())))
+    if ch_axis is None:
+        return vmax.reshape(()), (None if vmin is None else vmin.reshape(()))
+    return vmax, vmin
+
+
+def observe_qparams(x, n_bits, signed, ch_axis=None, allow_offset=True, scale_eps=0.0):
+    """Observer + the scale/offset arithmetic of ops.py:20-34 / :121-140, entirely on device.
+    Returns (scale, offset): 0-dim tensors per tensor, [1,..,C,..,1] per channel."""
+    N.require_gpu(x)
+    x = x.contiguous()
+    outer, ch, inner = _obs_geometry(x, ch_axis)
+    scale = torch.empty(ch, dtype=torch.float32, device=x.device)
+    offset = torch.empty(ch, dtype=torch.float32, device=x.device)
+    nb = N.lib.dlmcq_minmax_scratch_bytes(outer, ch, inner)
+    sc = _scratch(nb, x.device)
+    PROFILE.launch("observer", x.numel() * 4, lambda: N.check(N.lib.dlmcq_observe_qparams_f32(
+        N.ptr(x), N.ptr(scale), N.ptr(offset), outer, ch, inner, int(n_bits), int(bool(signed)),
+        int(bool(allow_offset)), float(scale_eps), N.ptr(sc), sc.numel() * 4, N.stream_ptr())))
+    if ch_axis is None:
+        return scale.reshape(()), offset.reshape(())
+    shape = channel_shape(x, ch_axis)
+    return scale.reshape(shape), offset.reshape(shape)
+
+
+def qparams_from_minmax(vmax, vmin, n_bits, signed, allow_offset=True, min_is_negated=False, scale_eps=0.0):
+    """The arithmetic tail alone (after a cross-rank all-reduce of [max | -min])."""
+    N.require_gpu(vmax)
+    vmax = vmax.contiguous()
+    vmin = None if vmin is None else vmin.contiguous()
+    ch = vmax.numel()
+    scale = torch.empty(ch, dtype=torch.float32, device=vmax.device)
+    offset = torch.empty(ch, dtype=torch.float32, device=vmax.device)
+    N.check(N.lib.dlmcq_qparams_from_minmax(N.ptr(vmax), N.ptr(vmin), N.ptr(scale), N.ptr(offset), ch, int(n_bits),
+                                            int(bool(signed)), int(bool(allow_offset)), int(bool(min_is_negated)),
+                                            float(scale_eps), N.stream_ptr()))
+    return scale, offset
+
+
+def pack_int4(codes):
+    N.require_gpu(codes)
+    codes = codes.contiguous().view(torch.int8)
+    n = codes.numel()
+    packed = torch.empty((n + 1) // 2, dtype=torch.uint8, device=codes.device)
+    N.check(N.lib.dlmcq_pack_int4(N.ptr(codes), N.ptr(packed), n, N.stream_ptr()))
+    return packed
+
+
+def unpack_int4(packed, n, signed):
+    N.require_gpu(packed)
+    codes = torch.empty(n, dtype=torch.int8, device=packed.device)
+    N.check(N.lib.dlmcq_unpack_int4(N.ptr(packed.contiguous()), N.ptr(codes), n, int(bool(signed)), N.stream_ptr()))
+    return codes if signed else codes.view(torch.uint8)
+
+
+def fake_quant_backward(x, gy, scale, offset, lo, hi, g, ch_axis=None, want_gx=True, want_gscale=True):
+    """Backward of FORM_QBASE: (gx, gscale[C]) - gx bit-exact with autograd, gscale a deterministic tree sum."""
+    N.require_gpu(x, gy)
+    x, gy = x.contiguous(), gy.contiguous()
+    scale, offset = _f32c(scale, x), _f32c(offset, x)
+    outer, ch, inner = geometry(x, scale, ch_axis)
+    if offset is not None and offset.numel() != scale.numel():
+        offset = offset.reshape(1).expand(scale.numel()).contiguous()
+    gx = torch.empty_like(x) if want_gx else None
+    gs = torch.empty(ch, dtype=torch.float32, device=x.device) if want_gscale else None
+    nb = N.lib.dlmcq_fq_bwd_scratch_bytes(outer, ch, inner)
+    sc = _scratch(nb, x.device)
+    N.check(N.lib.dlmcq_fake_quant_bwd_f32(N.ptr(x), N.ptr(gy), N.ptr(gx), N.ptr(gs), N.ptr(scale), N.ptr(offset), outer,
+                                           ch, inner, int(lo), int(hi), float(g), N.ptr(sc), sc.numel() * 4,
+                                           N.stream_ptr()))
+    return gx, gs
+
+
+def rootq_weight(w, upper, lower, lo, hi):
+    """RootQ weight forward; `upper`/`lower` are 0-dim (or 1-element) device tensors."""
+    N.require_gpu(w)
+    w = w.contiguous()
+    bounds = torch.stack([upper.detach().reshape(()).float(), lower.detach().reshape(()).float()]).to(w.device)
+    y = torch.empty_like(w)
+    N.check(N.lib.dlmcq_rootq_weight_f32(N.ptr(w), N.ptr(y), N.ptr(bounds), w.numel(), int(lo), int(hi), N.stream_ptr()))
+    return y

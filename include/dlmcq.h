@@ -1,0 +1,178 @@
+/*
+ * dlmcq.h - C ABI of the MI355X (gfx950) fake-quantize path.
+ *
+ * This is the drop-in boundary for DLMC-QUANT's fake-quantize hot path.  The reference has no
+ * FFI of its own: the path is a chain of ATen elementwise/reduction ops issued from Python
+ * (reference files cited per entry point below, relative to the reference checkout).  Each entry
+ * point here replaces one such chain with ONE hand-written HIP kernel (or a two-launch
+ * reduce/finalize pair); the Python layer in `dlmc-quant_amd/dlmc/` binds them with ctypes and
+ * re-exports the reference's own names (`quantize`, `emulate_quantize`, `get_qparams_tensor`,
+ * `QConv2d`, ... see INTEGRATION.md).
+ *
+ * Contract:
+ *   - plain pointers and sizes only; no torch / C++ types cross the boundary;
+ *   - every buffer (x, y, codes, scale, offset, scratch) is caller-allocated DEVICE memory; the
+ *     library owns nothing and keeps no global mutable state (all functions are re-entrant);
+ *   - all work is enqueued asynchronously on the caller's `stream` (a hipStream_t passed as
+ *     void*), on the caller's current device; nothing here synchronises the device or allocates,
+ *     so every entry point is hipGraph-capturable;
+ *   - return value: 0 = success; < 0 = a DLMCQ_E* argument error (nothing was launched);
+ *     > 0 = the hipError_t of the failed launch.  No exception or abort crosses the boundary.
+ *
+ * Tensor addressing.  Every elementwise entry point sees its tensor as (outer, channels, inner),
+ * contiguous, with one (scale, offset) pair per channel:
+ *     per-tensor            : outer = 1, channels = 1, inner = numel
+ *     KCRS weights, axis 0  : outer = 1, channels = K, inner = C*R*S      (scale [K,1,1,1])
+ *     NCHW activations, ax 1: outer = N, channels = C, inner = H*W        (scale [1,C,1,1])
+ *     (N,C) activations     : outer = N, channels = C, inner = 1
+ * No transpose copy is ever made (the reference materialises one: ops.py:112-118).
+ */
+#ifndef DLMCQ_H
+#define DLMCQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLMCQ_VERSION 100 /* 0.1.0 */
+
+typedef void* dlmcq_stream_t; /* hipStream_t */
+
+/* ---- error codes (negative; positive values are hipError_t) ---- */
+#define DLMCQ_OK 0
+#define DLMCQ_EINVAL (-1)       /* null pointer, negative size, lo > hi, unknown enum value */
+#define DLMCQ_ERANGE (-2)       /* a size exceeds what the kernels index (see each function) */
+#define DLMCQ_ESCRATCH (-3)     /* scratch buffer too small or missing */
+#define DLMCQ_EALIGN (-4)       /* a pointer violates its stated alignment */
+
+/* ---- fake-quant forms: the five clamp-round-dequant expressions of the reference ----
+ * r(v) = rint(v) (round half to even); R(v) = (r(v) - v) + v, the forward value of the
+ * reference's `round_pass` (utils.py:29-32): equal to r(v) but -0 -> +0 and +-inf -> NaN.
+ * clamp() propagates NaN like torch.clamp.  All arithmetic is IEEE fp32, no FMA contraction. */
+#define DLMCQ_FORM_EMULATE 0   /* utils.py:1-11 emulate_quantize:
+                                  q = clamp(r((x-o)/(s+1e-7)), lo, hi);       y = q*s + o       */
+#define DLMCQ_FORM_QBASE 1     /* modules/base.py:96-102,131-133 (QBase.forward):
+                                  s^ = (s - s*g) + s*g  (grad_scale, utils.py:24-27)
+                                  q = R(clamp((x-o)/s^, lo, hi));              y = q*s^ + o      */
+#define DLMCQ_FORM_ZEROPOINT 2 /* FSPTQuant/base.py:108-109 (FSPTQ activations):
+                                  q = clamp(R(x/s) + zp, lo, hi);              y = (q - zp)*s    */
+#define DLMCQ_FORM_SYMMETRIC 3 /* FSPTQuant/base.py:149-152 (FSPTQ weights; offset unused):
+                                  q = clamp(R(x/s), lo, hi);                   y = q*s           */
+#define DLMCQ_FORM_ROOTQ_ACT 4 /* RootQ/base.py:106-111 + RootQ/function.py:15-20 (offset unused):
+                                  u = s*(hi-lo); t = x + relu(0-x); t = t - relu(t-u)
+                                  q = R(t/s);                                  y = q*s           */
+#define DLMCQ_FORM_COUNT 5
+
+/* ---- what is written to `y` ---- */
+#define DLMCQ_Y_DEQUANT 0 /* the fake-quantised value y */
+#define DLMCQ_Y_CODES 1   /* the integer code q as fp32 (reference `quantize`, utils.py:1-2) */
+
+/* ---- integer code emission (no reference counterpart: it keeps codes in fp32) ---- */
+#define DLMCQ_CODES_NONE 0
+#define DLMCQ_CODES_I8 1  /* one byte per element: int8 when lo < 0, uint8 otherwise */
+#define DLMCQ_CODES_P4 2  /* two codes per byte, element 2i in the low nibble, 2i+1 in the high
+                             nibble; two's-complement nibbles when lo < 0.  Needs -8<=lo, hi<=15 */
+
+int dlmcq_version(void);
+const char* dlmcq_strerror(int code);
+
+/*
+ * Fake-quantise x -> y (and/or integer codes) in one pass: 4 B read + 4 B written per element
+ * (+1 B int8 codes, +0.5 B packed int4).  Replaces the 6-9 separate ATen passes of
+ * utils.py:9-11 / modules/base.py:102,133 / FSPTQuant/base.py:108-109,149-152 / RootQ/base.py:108-111.
+ *   x, y     : fp32 [outer*channels*inner]; y may alias x; y may be NULL when only codes are wanted
+ *   codes    : NULL or the buffer selected by codes_kind (4-byte aligned)
+ *   scale    : fp32 [channels]        offset: fp32 [channels] or NULL (= 0)
+ *   ste_g    : DLMCQ_FORM_QBASE only - the `g` of grad_scale; 0 gives s^ = s
+ * Any pointer alignment is accepted (16-byte aligned x/y take the 128-bit path).
+ * DLMCQ_ERANGE if channels*inner >= 2^31 with channels > 1, or the launch would exceed 2^31 blocks.
+ */
+int dlmcq_fake_quant_f32(const float* x, float* y, void* codes, const float* scale,
+                         const float* offset, int64_t outer, int64_t channels, int64_t inner,
+                         int32_t lo, int32_t hi, int32_t form, int32_t y_kind, int32_t codes_kind,
+                         float ste_g, dlmcq_stream_t stream);
+
+/*
+ * Dequantise stored integer codes: the second half of every form above (reference `dequantize`,
+ * utils.py:5-6, for forms EMULATE/QBASE).  codes_kind I8 or P4; `is_signed` selects int8/uint8 or
+ * the nibble sign extension.  For DLMCQ_FORM_QBASE pass the same ste_g as at quantisation.
+ */
+int dlmcq_dequant_codes_f32(const void* codes, float* y, const float* scale, const float* offset,
+                            int64_t outer, int64_t channels, int64_t inner, int32_t form,
+                            int32_t codes_kind, int32_t is_signed, float ste_g,
+                            dlmcq_stream_t stream);
+
+/* Reference `dequantize` on fp32 codes (utils.py:5-6): y = q*s + o. */
+int dlmcq_dequant_f32(const float* q, float* y, const float* scale, const float* offset,
+                      int64_t outer, int64_t channels, int64_t inner, dlmcq_stream_t stream);
+
+/* ---- observer (ops.py:20-34 per tensor, ops.py:112-140 per channel) ---- */
+#define DLMCQ_MINMAX_ABSMAX 0 /* out_max[c] = max|x|;             out_min untouched (may be NULL) */
+#define DLMCQ_MINMAX_MINMAX 1 /* out_max[c] = max x, out_min[c] = min x                           */
+#define DLMCQ_MINMAX_NEGMIN 2 /* out_max[c] = max x, out_min[c] = -min x: [max | -min] is then one
+                                 flat vector for a single all_reduce(MAX) across ranks (C2)       */
+
+/* Bytes of device scratch the observer needs for this shape (partials of the first stage). */
+size_t dlmcq_minmax_scratch_bytes(int64_t outer, int64_t channels, int64_t inner);
+
+/*
+ * One read of x (4 B per element), NaN-propagating like torch.max/min.  Two launches: a partial
+ * reduction (wave shuffles -> LDS -> one partial per block) and a finalize over the partials.
+ * Deterministic (no atomics); results do not depend on the launch geometry.
+ */
+int dlmcq_minmax_f32(const float* x, float* out_max, float* out_min, int64_t outer,
+                     int64_t channels, int64_t inner, int32_t mode, void* scratch,
+                     size_t scratch_bytes, dlmcq_stream_t stream);
+
+/*
+ * The arithmetic tail of quantize_minmax_{tensor,channel} on device (no host sync):
+ *   signed  : scale = vmax / (2^(b-1)-1)              offset = 0         (vmax = max|x|)
+ *   unsigned: scale = (vmax - vmin) / (2^b-1)         offset = vmin      (allow_offset != 0)
+ *             scale = (vmax - 0) / (2^b-1)            offset = 0         (allow_offset == 0)
+ * then scale += scale_eps when scale_eps != 0 (FSPTQuant/base.py:129 adds 1e-6).
+ * `min_is_negated` != 0 when vmin holds -min (DLMCQ_MINMAX_NEGMIN, after the all-reduce).
+ */
+int dlmcq_qparams_from_minmax(const float* vmax, const float* vmin, float* scale, float* offset,
+                              int64_t channels, int32_t n_bits, int32_t is_signed,
+                              int32_t allow_offset, int32_t min_is_negated, float scale_eps,
+                              dlmcq_stream_t stream);
+
+/* dlmcq_minmax_f32 + dlmcq_qparams_from_minmax fused into the same two launches. */
+int dlmcq_observe_qparams_f32(const float* x, float* scale, float* offset, int64_t outer,
+                              int64_t channels, int64_t inner, int32_t n_bits, int32_t is_signed,
+                              int32_t allow_offset, float scale_eps, void* scratch,
+                              size_t scratch_bytes, dlmcq_stream_t stream);
+
+/* ---- sub-byte pack / unpack (BASELINE config 5; layout as DLMCQ_CODES_P4) ---- */
+int dlmcq_pack_int4(const int8_t* codes, uint8_t* packed, int64_t n, dlmcq_stream_t stream);
+int dlmcq_unpack_int4(const uint8_t* packed, int8_t* codes, int64_t n, int32_t is_signed,
+                      dlmcq_stream_t stream);
+
+/*
+ * Backward of DLMCQ_FORM_QBASE as autograd executes it through modules/base.py:96-102 (closed
+ * form: modules/function.py:37-49).  With v = (x-o)/s^, inside = [lo <= v <= hi]:
+ *   gx       = inside ? (gy*s^)/s^ : +0                      (bit-exact with autograd)
+ *   gscale[c]= g * sum(gy*q - inside*(gy*s^)*(v/s^))          (fp32 tree sum, deterministic)
+ * gx may alias gy; gx or gscale may be NULL.  scratch: dlmcq_fq_bwd_scratch_bytes().
+ */
+size_t dlmcq_fq_bwd_scratch_bytes(int64_t outer, int64_t channels, int64_t inner);
+int dlmcq_fake_quant_bwd_f32(const float* x, const float* gy, float* gx, float* gscale,
+                             const float* scale, const float* offset, int64_t outer,
+                             int64_t channels, int64_t inner, int32_t lo, int32_t hi, float ste_g,
+                             void* scratch, size_t scratch_bytes, dlmcq_stream_t stream);
+
+/*
+ * RootQ weight forward (RootQ/base.py:146-155 + RootQ/function.py:15-32,58-67), per tensor.
+ * `bounds` is a device array {upper, lower}.  The forward value does not depend on alpha (it only
+ * shapes the gradient), so alpha is not an input.  y = ((sgn+1)/2 + interval)*delta + lower.
+ */
+int dlmcq_rootq_weight_f32(const float* w, float* y, const float* bounds, int64_t n, int32_t lo,
+                           int32_t hi, dlmcq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLMCQ_H */
