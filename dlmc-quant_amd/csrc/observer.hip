@@ -311,7 +311,7 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void qparams_kernel(const float* __res
   float s, o;
   qparams_tail(mx, mn, mx, f, s, o);
   f.out_a[c] = s;
-  f.out_b[c] = o;
+  if (f.out_b) f.out_b[c] = o;
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -466,6 +466,23 @@ extern "C" int dlmcq_qparams_from_minmax(const float* vmax, const float* vmin, f
   f.is_signed = is_signed;
   f.allow_offset = allow_offset;
   f.scale_eps = scale_eps;
+  const int g = (int)((channels + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK);
+  hipLaunchKernelGGL(qparams_kernel, dim3(g), dim3(DLMCQ_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), vmax, vmin,
+                     channels, min_is_negated, f);
+  return launch_status();
+}
+
+extern "C" int dlmcq_span_scale_f32(const float* vmax, const float* vmin, float* scale, int64_t channels, float span,
+                                    int32_t min_is_negated, dlmcq_stream_t stream) {
+  if (channels < 1 || !(span > 0.0f)) return DLMCQ_EINVAL;
+  if (!vmax || !vmin || !scale) return DLMCQ_EINVAL;
+  Finalize f{};
+  f.out_a = scale;
+  f.out_b = nullptr;
+  f.qparams = 1;
+  f.qmax = span;
+  f.is_signed = 0;
+  f.allow_offset = 1;
   const int g = (int)((channels + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK);
   hipLaunchKernelGGL(qparams_kernel, dim3(g), dim3(DLMCQ_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), vmax, vmin,
                      channels, min_is_negated, f);

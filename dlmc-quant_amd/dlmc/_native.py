@@ -29,6 +29,7 @@ SIGNATURES = {
     "dlmcq_minmax_scratch_bytes": (_sz, [_i64, _i64, _i64]),
     "dlmcq_minmax_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i32, _p, _sz, _p]),
     "dlmcq_qparams_from_minmax": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f32, _p]),
+    "dlmcq_span_scale_f32": (ctypes.c_int, [_p, _p, _p, _i64, _f32, _i32, _p]),
     "dlmcq_observe_qparams_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _p, _sz, _p]),
     "dlmcq_pack_int4": (ctypes.c_int, [_p, _p, _i64, _p]),
     "dlmcq_unpack_int4": (ctypes.c_int, [_p, _p, _i64, _i32, _p]),

@@ -1,0 +1,185 @@
+"""Machinery shared by the three wrapper families (QBase / FSPTQBase / RootQBase).
+
+* autograd Functions whose FORWARD is always one HIP kernel launch; the QBase form also has a HIP
+  backward, the other forms recompute the reference's own op chain on device under autograd for
+  the backward pass (training / calibration only - the steady-state forward never does);
+* the observer, with the one exchange step the path has under data parallelism: an all-reduce(MAX)
+  of the packed [max | -min] vector so that every rank derives identical (scale, offset) from the
+  GLOBAL batch (the reference has no such step: ranks calibrate on local batches and diverge,
+  modules/base.py:82-94);
+* host-side tracking of the `*_init_state` buffers, so the steady-state forward never reads a device
+  scalar (the reference does `if self.in_init_state == 0` - a device->host sync - per layer per step).
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from ... import _native as N
+from . import kernels as K
+
+# ---------------------------------------------------------------------------- conv / linear
+_PAIR0 = (0, 0)
+
+
+def conv_forward(mod, x_q, w_q):
+    """F.conv2d on the fake-quantised operands; non-zero padding modes pre-pad (as nn.Conv2d does)."""
+    if mod.padding_mode != "zeros":
+        x_q = F.pad(x_q, mod._reversed_padding_repeated_twice, mode=mod.padding_mode)
+        return F.conv2d(x_q, w_q, mod.bias, mod.stride, _PAIR0, mod.dilation, mod.groups)
+    return F.conv2d(x_q, w_q, mod.bias, mod.stride, mod.padding, mod.dilation, mod.groups)
+
+
+def linear_forward(mod, x_q, w_q):
+    return F.linear(x_q, w_q, mod.bias)
+
+
+# ------------------------------------------------------------------- STE helpers (composite)
+def _ste(value_fn, x):
+    y = value_fn(x)
+    return (y - x).detach() + x
+
+
+def _composite(form, x, scale, offset, lo, hi, g):
+    """The reference's own op chain for one form, on device tensors, differentiable.  Used only to
+    obtain gradients (backward of the HIP forward); its forward value is discarded."""
+    if form == N.FORM_EMULATE:
+        q = ((x - offset) / (scale + 1e-7)).round().clamp(lo, hi)
+        return q * scale + offset
+    if form == N.FORM_QBASE:
+        sg = scale * g
+        s_hat = (scale - sg).detach() + sg
+        return _ste(torch.round, ((x - offset) / s_hat).clamp(lo, hi)) * s_hat + offset
+    if form == N.FORM_ZEROPOINT:
+        q = (_ste(torch.round, x / scale) + offset).clamp(lo, hi)
+        return (q - offset) * scale
+    if form == N.FORM_SYMMETRIC:
+        return _ste(torch.round, x / scale).clamp(lo, hi) * scale
+    if form == N.FORM_ROOTQ_ACT:
+        upper = scale * (hi - lo)
+        xc = x + F.relu(0 - x)
+        xc = xc - F.relu(xc - upper)
+        return _ste(torch.round, xc / scale) * scale
+    raise ValueError(form)
+
+
+class FakeQuantFn(torch.autograd.Function):
+    """y = fake_quant(x; scale, offset) for any form.  Forward: one HIP launch.  Backward: HIP for
+    FORM_QBASE, composite recompute otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, scale, offset, lo, hi, form, g):
+        ctx.meta = (lo, hi, form, g)
+        ctx.save_for_backward(x, scale, offset)
+        return K.fake_quant(x, scale.detach(), offset, lo, hi, form, g=g)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lo, hi, form, g = ctx.meta
+        x, scale, offset = ctx.saved_tensors
+        need_x, need_s = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx = gs = None
+        if form == N.FORM_QBASE:
+            gx, gsv = K.fake_quant_backward(x, gy, scale.detach(), offset, lo, hi, g, want_gx=need_x, want_gscale=need_s)
+            if need_s:
+                gs = gsv.reshape(scale.shape)
+        else:
+            with torch.enable_grad():
+                xr = x.detach().requires_grad_(need_x)
+                sr = scale.detach().requires_grad_(need_s)
+                y = _composite(form, xr, sr, offset, lo, hi, g)
+                ins = [t for t, n in ((xr, need_x), (sr, need_s)) if n]
+                grads = list(torch.autograd.grad(y, ins, gy, allow_unused=True))
+            if need_x:
+                gx = grads.pop(0)
+            if need_s:
+                gs = grads.pop(0)
+        return gx, gs, None, None, None, None, None
+
+
+def fake_quant(x, scale, offset, lo, hi, form, g=0.0):
+    """Fake-quantise with autograd when (and only when) something upstream wants gradients."""
+    if offset is None:
+        offset = torch.zeros((), dtype=torch.float32, device=x.device)
+    elif not isinstance(offset, torch.Tensor) or offset.device != x.device or offset.dtype != torch.float32:
+        offset = torch.as_tensor(offset, dtype=torch.float32).to(x.device)
+    if torch.is_grad_enabled() and (x.requires_grad or scale.requires_grad):
+        return FakeQuantFn.apply(x, scale, offset, lo, hi, form, g)
+    return K.fake_quant(x, scale.detach(), offset, lo, hi, form, g=g)
+
+
+# --------------------------------------------------------------- observer + data-parallel sync
+def sync_enabled():
+    return os.environ.get("DLMC_SYNC_OBSERVER", "1") != "0"
+
+
+def allreduce_minmax(vmax, neg_vmin=None, group=None):
+    """The path's only collective (C2): one all_reduce(MAX) over the packed [max | -min] vector.
+    Exact and order-independent, so every rank ends with the single-GPU result over the whole batch.
+    Works on any backend (RCCL on GPUs, gloo in the CPU tests)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return vmax, neg_vmin
+    if neg_vmin is None:
+        buf = vmax.contiguous()
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+        return buf, None
+    n = vmax.numel()
+    buf = torch.cat([vmax.reshape(-1), neg_vmin.reshape(-1)])
+    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+    return buf[:n].reshape(vmax.shape), buf[n:].reshape(neg_vmin.shape)
+
+
+def observe_minmax(x, n_bits, signed, ch_axis=None, allow_offset=True, scale_eps=0.0, sync=False):
+    """quantize_minmax_{tensor,channel} on device.  `sync=True` (activations under data parallelism)
+    inserts the all-reduce between the reduction and the scale/offset arithmetic."""
+    import torch.distributed as dist
+    if not (sync and sync_enabled() and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return K.observe_qparams(x, n_bits, signed, ch_axis=ch_axis, allow_offset=allow_offset, scale_eps=scale_eps)
+    if signed:
+        vmax, _ = K.minmax(x, ch_axis=ch_axis, mode=N.MINMAX_ABSMAX)
+        vmax, _ = allreduce_minmax(vmax.reshape(-1))
+        s, o = K.qparams_from_minmax(vmax, None, n_bits, True, scale_eps=scale_eps)
+    else:
+        vmax, nmin = K.minmax(x, ch_axis=ch_axis, mode=N.MINMAX_NEGMIN)
+        vmax, nmin = allreduce_minmax(vmax.reshape(-1), nmin.reshape(-1))
+        s, o = K.qparams_from_minmax(vmax, nmin, n_bits, False, allow_offset=allow_offset, min_is_negated=True,
+                                     scale_eps=scale_eps)
+    if ch_axis is None:
+        return s.reshape(()), o.reshape(())
+    shape = K.channel_shape(x, ch_axis)
+    return s.reshape(shape), o.reshape(shape)
+
+
+# ------------------------------------------------------------------- init-state bookkeeping
+class InitState:
+    """Host mirror of the `in_init_state` / `wt_init_state` buffers.  The buffer stays the source of
+    truth for checkpoints; the mirror is refreshed from it only when it may have changed behind our
+    back (construction, load_state_dict, explicit invalidate), never in the steady state."""
+
+    def __init__(self):
+        self._known = {}
+
+    def ready(self, mod, name):
+        v = self._known.get(name)
+        if v is None:
+            v = bool(getattr(mod, name).detach().reshape(-1)[0].item() != 0)  # one sync, then cached
+            self._known[name] = v
+        return v
+
+    def mark(self, mod, name, value=True):
+        getattr(mod, name).fill_(1 if value else 0)
+        self._known[name] = bool(value)
+
+    def invalidate(self):
+        self._known = {}
+
+
+def set_scale(param, value):
+    """`param.data.copy_(value)`, growing the Parameter when a per-channel scale arrives for a
+    per-tensor-shaped Parameter (the reference raises there: SURVEY.md defect 3)."""
+    value = value.detach()
+    if param.numel() == value.numel():
+        param.data.copy_(value.reshape(param.shape))
+    else:
+        param.data = value.clone().to(param.device)

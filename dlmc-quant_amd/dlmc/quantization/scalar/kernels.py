@@ -13,7 +13,7 @@ from ..._native import (CODES_I8, CODES_NONE, CODES_P4, FORM_EMULATE, FORM_QBASE
                         Y_CODES, Y_DEQUANT)
 
 __all__ = ["fake_quant", "dequant_codes", "dequant", "minmax", "observe_qparams", "qparams_from_minmax",
-           "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
+           "span_scale", "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
            "PROFILE"]
 
 
@@ -201,6 +201,16 @@ def qparams_from_minmax(vmax, vmin, n_bits, signed, allow_offset=True, min_is_ne
                                             int(bool(signed)), int(bool(allow_offset)), int(bool(min_is_negated)),
                                             float(scale_eps), N.stream_ptr()))
     return scale, offset
+
+
+def span_scale(vmax, neg_vmin, span):
+    """(max - min) / span with a true IEEE division, from the [max | -min] pair of `minmax(NEGMIN)`."""
+    N.require_gpu(vmax, neg_vmin)
+    vmax, neg_vmin = vmax.contiguous(), neg_vmin.contiguous()
+    scale = torch.empty(vmax.numel(), dtype=torch.float32, device=vmax.device)
+    N.check(N.lib.dlmcq_span_scale_f32(N.ptr(vmax), N.ptr(neg_vmin), N.ptr(scale), vmax.numel(), float(span), 1,
+                                       N.stream_ptr()))
+    return scale
 
 
 def pack_int4(codes):

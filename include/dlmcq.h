@@ -140,6 +140,13 @@ int dlmcq_qparams_from_minmax(const float* vmax, const float* vmin, float* scale
                               int32_t allow_offset, int32_t min_is_negated, float scale_eps,
                               dlmcq_stream_t stream);
 
+/*
+ * RootQ activation initialisation (RootQ/base.py:80): scale[c] = (vmax[c] - vmin[c]) / span with a true
+ * IEEE division (span = hi - lo of the format).  `min_is_negated` as above.
+ */
+int dlmcq_span_scale_f32(const float* vmax, const float* vmin, float* scale, int64_t channels, float span,
+                         int32_t min_is_negated, dlmcq_stream_t stream);
+
 /* dlmcq_minmax_f32 + dlmcq_qparams_from_minmax fused into the same two launches. */
 int dlmcq_observe_qparams_f32(const float* x, float* scale, float* offset, int64_t outer,
                               int64_t channels, int64_t inner, int32_t n_bits, int32_t is_signed,

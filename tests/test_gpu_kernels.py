@@ -293,8 +293,10 @@ def test_observer_vs_oracle_shapes(K, ch_axis):
             # raw min/max and the packed [max | -min] form used by the cross-rank all-reduce
             mx, mn = K.minmax(xd, ch_axis=ch_axis, mode=N().MINMAX_NEGMIN)
             red = tuple(i for i in range(x.dim()) if i != ch_axis) if ch_axis is not None else None
-            values_equal(mx, x.amax(dim=red) if red is not None else x.max())
-            values_equal(mn, -(x.amin(dim=red) if red is not None else x.min()))
+            amax = x.max() if red is None else (x.amax(dim=red) if red else x)
+            amin = x.min() if red is None else (x.amin(dim=red) if red else x)
+            values_equal(mx, amax)
+            values_equal(mn, -amin)
             s2, o2 = K.qparams_from_minmax(mx.reshape(-1), mn.reshape(-1), 8, signed, min_is_negated=True) if not signed \
                 else K.qparams_from_minmax(K.minmax(xd, ch_axis=ch_axis, mode=N().MINMAX_ABSMAX)[0].reshape(-1), None, 8, True)
             values_equal(s2, ws, "split observer scale")
@@ -369,13 +371,13 @@ def test_full_size_properties(K):
     W = torch.randn(256, 256, 3, 3, device=DEV) * math.sqrt(2 / 2304)
     # observers
     s_t, o_t = K.observe_qparams(A, 8, True)
-    assert float(s_t) == float(A.abs().max() / 127)
+    assert float(s_t) == float(A.abs().max().cpu() / 127)  # divide on the CPU: torch-GPU multiplies by 1/127
     s_c, o_c = K.observe_qparams(A, 8, False, ch_axis=1)
     mx, mn = A.amax(dim=(0, 2, 3)), A.amin(dim=(0, 2, 3))
-    values_equal(s_c.reshape(-1), (mx - mn) / 255, "per-channel scale")
+    values_equal(s_c.reshape(-1), (mx - mn).cpu() / 255, "per-channel scale")
     values_equal(o_c.reshape(-1), mn, "per-channel offset")
     s_w, _ = K.observe_qparams(W, 8, True, ch_axis=0)
-    values_equal(s_w.reshape(-1), W.abs().amax(dim=(1, 2, 3)) / 127)
+    values_equal(s_w.reshape(-1), W.abs().amax(dim=(1, 2, 3)).cpu() / 127)
     # per-tensor QBase form on A
     gg = 1 / math.sqrt(A.numel() * 127)
     y = K.fake_quant(A, s_t, o_t, -127, 127, n.FORM_QBASE, g=gg)

@@ -1,0 +1,141 @@
+"""Host-side logic that needs no GPU: `quantize_model` (class swap, regex exclusion, per-layer
+overrides, state_dict layout), the benchmark layer tables, and the refusal to run on CPU tensors."""
+import copy
+import logging
+
+import pytest
+import torch
+from torch import nn
+
+import workloads as W
+from dlmc._native import DlmcqError
+from dlmc.quantization.scalar import FSPTQuant, RootQ, modules
+from dlmc.utils.access import attrsetter, get_layers, mark_modules
+from dlmc.utils.quantize import quantize_model
+
+CFG = {
+    "weight": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": True}},
+    "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": True}},
+    "exclude_layers": [],
+    "override_options": [{"layers": []}],
+}
+
+
+def small_net():
+    return nn.Sequential()  # placeholder replaced below
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 8, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(8)
+        self.layer1 = nn.Sequential(nn.Conv2d(8, 8, 3, padding=1, bias=False), nn.ReLU(), nn.Conv2d(8, 16, 1))
+        self.fc = nn.Linear(16, 10)
+
+    def forward(self, x):
+        x = self.layer1(self.bn1(self.conv1(x)))
+        return self.fc(x.mean(dim=(2, 3)))
+
+
+def test_layer_tables_match_the_survey():
+    want = {"resnet18": (21, 2183168, 11678912), "resnet50": (54, 10664448, 25502912),
+            "repvgg_a1": (23, 2459904, 12783296)}
+    for name, (layers, act, wt) in want.items():
+        rows = W.layer_table(W.MODELS[name](), torch.zeros(1, 3, 224, 224))
+        got = W.table_totals(rows)
+        assert got[:3] == (layers, act, wt), name
+    assert W.table_totals(W.layer_table(W.resnet50(), torch.zeros(1, 3, 224, 224)))[3] == 4089184256
+
+
+def test_get_layers_and_attrsetter():
+    net = Net()
+    assert get_layers(net, filter_types=(nn.Conv2d, nn.Linear)) == ["conv1", "layer1.0", "layer1.2", "fc"]
+    assert get_layers(net, filter_regexp="layer1") == ["layer1.0", "layer1.2"]
+    assert get_layers(net, filter_regexp="conv") == ["conv1"]          # re.match: anchored at the start
+    assert "bn1" in get_layers(net)                                     # every weight owner, like the reference
+    attrsetter("layer1.2")(net, nn.Identity())
+    assert isinstance(net.layer1[2], nn.Identity)
+    mark_modules(net)
+    assert net.layer1[0].name == "layer1.0"
+
+
+def test_quantize_model_swaps_in_place_and_keeps_parameters():
+    net = Net()
+    w_before = net.conv1.weight
+    quantize_model(net, copy.deepcopy(CFG), logging.getLogger("t"))
+    assert isinstance(net.conv1, modules.QConv2d) and isinstance(net.conv1, modules.QBase)
+    assert isinstance(net.layer1[0], modules.QConv2d) and isinstance(net.fc, modules.QLinear)
+    assert net.conv1.weight is w_before                                  # __dict__ carried over, not copied
+    assert isinstance(net.bn1, nn.BatchNorm2d)
+    keys = set(net.state_dict().keys())
+    for k in ("conv1.in_scale", "conv1.wt_scale", "conv1.in_init_state", "conv1.wt_init_state", "conv1.weight",
+              "conv1.bias", "fc.in_scale"):
+        assert k in keys
+    assert "conv1.in_offset" not in keys                                 # None until the first forward, as the reference
+    assert net.conv1.in_scale.shape == (1,) and net.conv1.in_init_state.shape == (1,)
+    assert (net.conv1.wt_min_val, net.conv1.wt_max_val) == (-127, 127)
+    assert hasattr(net.conv1, "reset_qparams") and hasattr(net.conv1, "_forward_func")
+    names = [n for n, _ in net.named_parameters()]
+    assert any(n.endswith("in_scale") for n in names) and any(n.endswith("wt_scale") for n in names)
+
+
+def test_quantize_model_exclude_and_override():
+    net = Net()
+    cfg = copy.deepcopy(CFG)
+    cfg["exclude_layers"] = ["conv1", "fc"]
+    cfg["override_options"] = [{"layers": ["layer1.2"], "options": {"weight": {"args": {"n_bits": 4}},
+                                                                      "input": {"type": "minmax_channel", "args": {"signed": False}}}}]
+    quantize_model(net, cfg, None)
+    assert type(net.conv1) is nn.Conv2d and type(net.fc) is nn.Linear
+    assert isinstance(net.layer1[0], modules.QConv2d)
+    q = net.layer1[2]
+    assert (q.wt_min_val, q.wt_max_val) == (-7, 7) and (q.in_min_val, q.in_max_val) == (0, 255)
+    assert q.qconfig["input"]["type"] == "minmax_channel" and q.qconfig["input"]["args"]["ch_axis"] == 1
+    assert net.layer1[0].qconfig["weight"]["args"]["n_bits"] == 8          # the default was not mutated
+    with pytest.raises(AssertionError):
+        bad = copy.deepcopy(CFG)
+        bad["override_options"] = [{"layers": ["fc"], "options": {}}, {"layers": ["fc"], "options": {}}]
+        quantize_model(Net(), bad, None)
+
+
+def test_families_and_state_dict_layout():
+    net = Net()
+    cfg = copy.deepcopy(CFG)
+    cfg["weight"].update(type="minmax_channel", recon_type="adaround")
+    quantize_model(net, cfg, None, quantization_type="FSPTQ")
+    assert isinstance(net.conv1, FSPTQuant.FSPTQConv2d) and isinstance(net.fc, FSPTQuant.FSPTQBase)
+    sd = net.state_dict()
+    assert sd["conv1.wt_scale"].shape == (8, 1, 1, 1) and sd["fc.wt_scale"].shape == (10, 1)
+    assert sd["conv1.wt_offset"].shape == (8, 1, 1, 1) and sd["conv1.in_offset"].shape == (1,)
+    assert sd["conv1.org_weight"].shape == net.conv1.weight.shape and sd["conv1.alpha"].shape == net.conv1.weight.shape
+    for m in ("change_quant_state", "reinit_parameters", "init_alpha", "get_soft_targets"):
+        assert hasattr(net.conv1, m)
+    net.conv1.change_quant_state(False, True)
+    assert (net.conv1.wt_quant, net.conv1.act_quant) == (False, True)
+
+    net = Net()
+    cfg = copy.deepcopy(CFG)
+    cfg["momentum"] = 0.05
+    quantize_model(net, cfg, None, quantization_type="RootQ")
+    assert isinstance(net.fc, RootQ.RootQLinear) and net.fc.momentum == 0.05
+    sd = net.state_dict()
+    for k in ("in_scale", "in_run_upper", "in_run_scale", "in_init_state", "wt_upper", "wt_lower", "wt_alpha",
+              "wt_run_upper", "wt_run_lower", "wt_init_state"):
+        assert sd["fc." + k].shape == ()
+    assert float(sd["fc.wt_upper"]) == 3.0 and float(sd["fc.wt_lower"]) == -4.0 and float(sd["fc.wt_alpha"]) == 0.25
+    with pytest.raises(NotImplementedError):
+        quantize_model(Net(), copy.deepcopy(CFG), None, quantization_type="BitMixer")
+
+
+def test_no_cpu_fallback_in_the_wrappers():
+    net = Net()
+    quantize_model(net, copy.deepcopy(CFG), None)
+    with pytest.raises(DlmcqError, match="no CPU fallback"):
+        net(torch.randn(2, 3, 8, 8))
+
+
+def test_unknown_qtype_raises_keyerror_like_the_reference():
+    from dlmc.quantization.scalar import ops
+    with pytest.raises(KeyError):
+        ops.get_qparams_tensor(torch.zeros(4), "no_such_estimator", n_bits=8, signed=True)
