@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ResNet-50 W8A8 per-channel fake-quant forward (BASELINE.json configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one forward of the quantised ResNet-50 (54 layers: fake-quant(input) [HIP], fake-quant(weight)
+[HIP], conv/linear [MIOpen/rocBLAS], plus the network's BN/ReLU/pool glue) over a batch of 512 synthetic
+224x224 images per GPU, scales frozen (the observer pass runs in the warm-up).  Activations and weights
+are resident in HBM when the timed region starts.  Weak scaling: every rank runs its own 512 images, no
+collective in the steady state (the observer all-reduce happens once, in the first warm-up step).
+
+One JSON line on rank 0.  Besides the contract fields:
+  roofline      the dominant kernel of the path - the per-tensor activation fake-quant (fq_tensor_kernel):
+                algorithmic bytes (8 B per element) / HIP-event duration, summed over its launches in the
+                timed region, on the launch stream
+  cpu_baseline  the CPU port of the same layer stack (oracle/), timed on this box's host cores on a
+                bounded sample (N = 1 only)
+  quant_path    images/s and GB/s of the fake-quant kernels alone (the HBM-bound part this project owns)
+"""
+import argparse
+import json
+import math
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dlmc-quant_amd")]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 measured for a float4 copy
+
+QCFG = {  # example/quantization/FSPTQ_config.yaml:40-53: W minmax_channel s8, A minmax_tensor u8
+    "weight": {"enable": True, "type": "minmax_channel", "recon_type": "None", "args": {"n_bits": 8, "signed": True}},
+    "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+    "exclude_layers": [], "override_options": [],
+}
+
+
+def usable_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box
+    shows 256 logical CPUs but grants a share of them; oversubscribing torch's pool is catastrophic)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(batch, budget_s=20.0):
+    """The reference's CPU path (port in oracle/ref_layers.py) on a bounded sample of the same workload."""
+    import workloads as W
+    from oracle.ref_layers import port_model
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(2333)
+    model = port_model(W.resnet50().eval(), "FSPTQ")
+    x = torch.randn(batch, 3, 224, 224)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        model(x)                      # calibration + warm-up
+        first = time.perf_counter() - t0
+        reps, spent = 0, 0.0
+        while reps < 1 or (spent + spent / reps < budget_s - first and reps < 50):
+            t0 = time.perf_counter()
+            model(x)
+            spent += time.perf_counter() - t0
+            reps += 1
+    return {"value": round(batch * reps / spent, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} forwards of batch {batch} (same ResNet-50 W8A8 layer stack, torch {torch.__version__} CPU, "
+                      f"{cores} threads), after 1 calibration forward"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU")
+    ap.add_argument("--model", default="resnet50", choices=["resnet18", "resnet50", "repvgg_a1"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import workloads as W
+    from dlmc.quantization.scalar import kernels as K
+    from dlmc.utils.quantize import quantize_model
+
+    torch.manual_seed(2333)  # the reference's seed; identical weights on every rank (replicated)
+    model = W.MODELS[args.model]().to(dev).eval()
+    quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ")
+    g = torch.Generator(device=dev).manual_seed(2333 + rank)
+    x = torch.randn(args.batch, 3, 224, 224, device=dev, generator=g)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):     # the first forward calibrates (observer + all-reduce)
+            model(x)
+        K.PROFILE.enabled = True
+        K.PROFILE.reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        K.PROFILE.enabled = False
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # per-kernel-family HIP-event durations of the timed region (rank 0's launches)
+    fam = {}
+    for tag, nbytes, a, b in K.PROFILE.records:
+        f = fam.setdefault(tag, {"launches": 0, "bytes": 0, "ms": 0.0})
+        f["launches"] += 1
+        f["bytes"] += nbytes
+        f["ms"] += a.elapsed_time(b)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    images = args.batch * world * args.steps
+    dom = fam.get("fq_tensor", {"launches": 0, "bytes": 0, "ms": 0.0})
+    achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
+    qbytes = sum(f["bytes"] for k, f in fam.items() if k.startswith("fq"))
+    qms = sum(f["ms"] for k, f in fam.items() if k.startswith("fq"))
+    out = {
+        "metric": "ResNet-50 W8A8 fake-quant fwd images/sec" if args.model == "resnet50" else f"{args.model} W8A8 fake-quant fwd images/sec",
+        "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} W8A8 per-channel fake-quant forward (FSPTQ forms: W minmax_channel s8, "
+                               f"A minmax_tensor u8), 224x224, batch {args.batch} per GPU, scales frozen",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel": "fq_tensor_kernel<ZEROPOINT> (per-tensor activation fake-quant)",
+                     "launches": dom["launches"],
+                     "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
+                     "algorithmic_bytes_per_launch_avg": dom["bytes"] // max(dom["launches"], 1)},
+        "quant_path": {"images_per_s": round(args.batch * args.steps / (qms * 1e-3), 1) if qms else None,
+                       "GBps": round(qbytes / (qms * 1e-3) / 1e9, 1) if qms else None,
+                       "ms_per_step": round(qms / args.steps, 3),
+                       "share_of_step": round(qms / args.steps / (elapsed / args.steps * 1e3), 4),
+                       "families": {k: {"launches": f["launches"], "GBps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)}
+                                    for k, f in fam.items() if f["ms"] > 0}},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,13 +120,17 @@ def allreduce_minmax(vmax, neg_vmin=None, group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return vmax, neg_vmin
-    if neg_vmin is None:
-        buf = vmax.contiguous()
-        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
-        return buf, None
     n = vmax.numel()
-    buf = torch.cat([vmax.reshape(-1), neg_vmin.reshape(-1)])
-    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+    buf = vmax.reshape(-1) if neg_vmin is None else torch.cat([vmax.reshape(-1), neg_vmin.reshape(-1)])
+    buf = buf.contiguous()
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        host = buf.cpu()                       # gloo rehearsal of the RCCL path (tests): stage through the host
+        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+        buf = host.to(buf.device)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+    if neg_vmin is None:
+        return buf.reshape(vmax.shape), None
     return buf[:n].reshape(vmax.shape), buf[n:].reshape(neg_vmin.shape)
 
 

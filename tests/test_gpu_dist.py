@@ -1,0 +1,83 @@
+"""Two data-parallel ranks (both on the box's single GPU, gloo rendezvous as a rehearsal of RCCL):
+each calibrates on its shard of the batch; thanks to the observer all-reduce every rank ends with the
+scales of a single process that saw the whole batch, and the steady-state forward needs no collective."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"weight": {"enable": True, "type": "minmax_channel", "recon_type": "None", "args": {"n_bits": 8, "signed": True}},
+       "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+       "exclude_layers": [], "override_options": []}
+
+
+def _net():
+    import copy
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "dlmc-quant_amd")]
+    from torch import nn
+    from dlmc.utils.quantize import quantize_model
+    torch.manual_seed(2333)
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.ReLU(),
+                        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 5)).cuda().eval()
+    return net, quantize_model, copy.deepcopy(CFG)
+
+
+def _batch():
+    return torch.randn(8, 3, 16, 16, generator=torch.Generator().manual_seed(7))
+
+
+def _scales(net):
+    return {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "scale" in k or "offset" in k}
+
+
+def _worker(rank, world, port, q, family):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net, quantize_model, cfg = _net()
+    cfg["momentum"] = 0.1
+    quantize_model(net, cfg, None, quantization_type=family)
+    shard = _batch().chunk(world, dim=0)[rank].cuda()
+    with torch.no_grad():
+        out = net(shard)
+    q.put((rank, _scales(net), out.cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("family", ["FSPTQ", None, "RootQ"])
+def test_sharded_calibration_equals_single_process(family):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, family)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, sc, out = q.get(timeout=240)
+        res[r] = (sc, out)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    net, quantize_model, cfg = _net()
+    cfg["momentum"] = 0.1
+    quantize_model(net, cfg, None, quantization_type=family)
+    with torch.no_grad():
+        full = net(_batch().cuda()).cpu()
+    want = _scales(net)
+    for r in (0, 1):
+        for k, v in want.items():
+            assert torch.equal(res[r][0][k], v), f"rank {r} {k}: {res[r][0][k]} vs {v}"
+    got = torch.cat([res[0][1], res[1][1]])
+    torch.testing.assert_close(got, full, rtol=1e-5, atol=1e-6)
