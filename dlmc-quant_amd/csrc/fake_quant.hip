@@ -4,9 +4,13 @@
 // ~25 VALU instructions (one IEEE fp32 division dominates): arithmetic intensity << machine balance,
 // so everything here is about the memory system:
 //   * 128-bit (dwordx4) loads and stores, lane i at base + 16*i: one 1 KiB request per wave-instruction;
-//   * U independent loads issued before the first use, so each wave keeps U KiB in flight;
-//   * per-channel (scale, offset) pairs staged ONCE per block into LDS - only the rows the block's
-//     chunk touches - and read back with a broadcast ds_read; the channel of an element comes from an
+//   * ONE-WAVE workgroups (64 threads), one float4 per lane, one chunk per workgroup and no grid-stride
+//     loop: measured on MI355X (tools/tune_fq.hip) this geometry streams 6.3-6.6 TB/s
+//     where 256-thread blocks with 4 loads per lane and a capped grid reach 5.6-6.0 - waves retire and are
+//     re-dispatched independently, which keeps the read and write streams evenly interleaved;
+//   * per-channel (scale, offset): a chunk that lies in one channel takes them through the scalar cache
+//     into SGPRs (free broadcast); a chunk that spans several channels stages exactly the rows it touches
+//     into LDS once and reads them back with a broadcast ds_read; the channel of an element comes from an
 //     exact multiply-shift division, never from a per-element integer divide or a transposed copy;
 //   * streaming (non-temporal) stores: the output is not re-read by this kernel.
 // Bit-exactness: true IEEE division, rintf (half-to-even), the reference's own operation order and its
@@ -100,29 +104,31 @@ __device__ __forceinline__ void store4(const FqOut& o, int64_t gidx, const f32x4
   }
 }
 
+constexpr int FQ_BLOCK = DLMCQ_WAVE;  // one-wave workgroups (see the header comment)
+
 // ------------------------------------------------------------------ per-tensor, 128-bit path
 // Grid-stride over chunks of 256*U float4.  n4 = numel/4; the 0-3 tail elements are finished by
 // the first lanes of block 0.
 template <int FORM, int U>
-__global__ __launch_bounds__(DLMCQ_BLOCK) void fq_tensor_kernel(const float* x, FqOut out,
+__global__ __launch_bounds__(FQ_BLOCK) void fq_tensor_kernel(const float* x, FqOut out,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ offset, int64_t n,
                                                                float lo, float hi, float g) {
   const ChanConst<FORM> c(scale[0], offset ? offset[0] : 0.0f, g, lo, hi);
   const int64_t n4 = n >> 2;
-  const int64_t nchunks = (n4 + DLMCQ_BLOCK * U - 1) / (DLMCQ_BLOCK * U);
+  const int64_t nchunks = (n4 + FQ_BLOCK * U - 1) / (FQ_BLOCK * U);
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);  // no __restrict__: y may alias x
   for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int64_t i0 = chunk * (DLMCQ_BLOCK * U) + threadIdx.x;
+    const int64_t i0 = chunk * (FQ_BLOCK * U) + threadIdx.x;
     f32x4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * DLMCQ_BLOCK;
+      const int64_t i = i0 + u * FQ_BLOCK;
       if (i < n4) v[u] = __builtin_nontemporal_load(x4 + i);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * DLMCQ_BLOCK;
+      const int64_t i = i0 + u * FQ_BLOCK;
       if (i < n4) {
         f32x4 q, y;
         fq4<FORM>(v[u], c, lo, hi, q, y);
@@ -160,59 +166,74 @@ struct ChanGeom {
 };
 
 template <int FORM, int U, bool ROW_UNIFORM>
-__global__ __launch_bounds__(DLMCQ_BLOCK) void fq_channel_kernel(const float* x, FqOut out,
-                                                                const float* __restrict__ scale,
-                                                                const float* __restrict__ offset, ChanGeom gm,
-                                                                float lo, float hi, float g) {
-  extern __shared__ float2 tbl[];  // [rows touched by this chunk] {scale, offset}
-  constexpr uint32_t CH = DLMCQ_BLOCK * U * 4;  // elements per chunk
+__global__ __launch_bounds__(FQ_BLOCK) void fq_channel_kernel(const float* x, FqOut out,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ offset, ChanGeom gm,
+                                                             float lo, float hi, float g) {
+  extern __shared__ float2 tbl[];  // [rows touched by this chunk] {scale, offset}; used only by mixed chunks
+  constexpr uint32_t CH = FQ_BLOCK * U * 4;  // elements per chunk
   const uint32_t slab_i = fdiv(blockIdx.x, gm.cpsdiv);
   const uint32_t cx = blockIdx.x - slab_i * gm.cps;
   const uint32_t slab = (uint32_t)gm.slab;
   const uint32_t e0 = cx * CH;
   const uint32_t e_end = (e0 + CH < slab) ? e0 + CH : slab;
   const uint32_t ch0 = fdiv(e0, gm.inner);
-  const uint32_t nrows = fdiv(e_end - 1, gm.inner) - ch0 + 1;
-  for (uint32_t t = threadIdx.x; t < nrows; t += DLMCQ_BLOCK)
-    tbl[t] = make_float2(scale[ch0 + t], offset ? offset[ch0 + t] : 0.0f);
+  const uint32_t ch1 = fdiv(e_end - 1, gm.inner);
 
+  // issue the streaming loads first; everything below overlaps their latency
   const int64_t base = (int64_t)slab_i * gm.slab;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x + base);
   f32x4 v[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const uint32_t e = e0 + (u * DLMCQ_BLOCK + threadIdx.x) * 4;
+    const uint32_t e = e0 + (u * FQ_BLOCK + threadIdx.x) * 4;
     if (e < slab) v[u] = __builtin_nontemporal_load(x4 + (e >> 2));
   }
+  __builtin_amdgcn_sched_barrier(0);  // keep the (dependent) scale fetch behind the data loads
+
+  if (ch0 == ch1) {
+    // The whole chunk lies in ONE channel (every chunk when inner >= 256*U): the workgroup is a single
+    // wave, so (scale, offset) come through the scalar cache into SGPRs and broadcast to all lanes for free.
+    const ChanConst<FORM> c(scale[ch0], offset ? offset[ch0] : 0.0f, g, lo, hi);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t e = e0 + (u * FQ_BLOCK + threadIdx.x) * 4;
+      if (e < slab) {
+        f32x4 q, y;
+        fq4<FORM>(v[u], c, lo, hi, q, y);
+        store4(out, base + e, q, y);
+      }
+    }
+    return;
+  }
+
+  // Mixed chunk (short rows: 14x14 / 7x7 planes, 1x1-conv weight rows, (N, C) activations): stage the rows
+  // it touches into LDS once, then each lane reads its channel's pair back with a broadcast ds_read.
+  const uint32_t nrows = ch1 - ch0 + 1;
+  for (uint32_t t = threadIdx.x; t < nrows; t += FQ_BLOCK)
+    tbl[t] = make_float2(scale[ch0 + t], offset ? offset[ch0 + t] : 0.0f);
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const uint32_t e = e0 + (u * DLMCQ_BLOCK + threadIdx.x) * 4;
+    const uint32_t e = e0 + (u * FQ_BLOCK + threadIdx.x) * 4;
     if (e < slab) {
       f32x4 q, y;
-      if (ROW_UNIFORM) {  // inner % 4 == 0: the four lanes of a float4 share one channel
-        const float2 so = tbl[fdiv(e, gm.inner) - ch0];
+      const uint32_t r0 = fdiv(e, gm.inner);
+      if (ROW_UNIFORM || r0 == fdiv(e + 3, gm.inner)) {  // inner % 4 == 0: a float4 never straddles rows
+        const float2 so = tbl[r0 - ch0];
         const ChanConst<FORM> c(so.x, so.y, g, lo, hi);
         fq4<FORM>(v[u], c, lo, hi, q, y);
       } else {
-        const uint32_t r0 = fdiv(e, gm.inner);
-        const uint32_t r3 = fdiv(e + 3, gm.inner);
-        if (r0 == r3) {
-          const float2 so = tbl[r0 - ch0];
-          const ChanConst<FORM> c(so.x, so.y, g, lo, hi);
-          fq4<FORM>(v[u], c, lo, hi, q, y);
-        } else {
-          float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-          float qv[4], yv[4];
+        float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        float qv[4], yv[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float2 so = tbl[fdiv(e + j, gm.inner) - ch0];
-            const ChanConst<FORM> c(so.x, so.y, g, lo, hi);
-            fq_one<FORM>(xv[j], c, lo, hi, qv[j], yv[j]);
-          }
-          q = f32x4{qv[0], qv[1], qv[2], qv[3]};
-          y = f32x4{yv[0], yv[1], yv[2], yv[3]};
+        for (int j = 0; j < 4; ++j) {
+          const float2 so = tbl[fdiv(e + j, gm.inner) - ch0];
+          const ChanConst<FORM> c(so.x, so.y, g, lo, hi);
+          fq_one<FORM>(xv[j], c, lo, hi, qv[j], yv[j]);
         }
+        q = f32x4{qv[0], qv[1], qv[2], qv[3]};
+        y = f32x4{yv[0], yv[1], yv[2], yv[3]};
       }
       store4(out, base + e, q, y);
     }
@@ -301,8 +322,8 @@ static int blocks_for(int64_t work_items, int per_block, int max_blocks) {
   return (int)b;
 }
 
-constexpr int FQ_U = 4;                       // float4 per thread per chunk: 4 KiB in flight per wave
-constexpr int FQ_MAX_BLOCKS = DLMCQ_CUS * 16; // per-tensor grid cap (grid-stride beyond it)
+constexpr int FQ_U = 1;                       // float4 per lane per chunk (see the header comment)
+constexpr int FQ_MAX_BLOCKS = 1 << 24;        // beyond 2^24 workgroups (2^32 elements) the kernels grid-stride
 
 template <int FORM>
 static int launch_fq(const float* x, const FqOut& out, const float* scale, const float* offset, int64_t outer,
@@ -311,14 +332,14 @@ static int launch_fq(const float* x, const FqOut& out, const float* scale, const
   const bool vec = aligned16(x) && (!out.y || aligned16(out.y)) && (!out.codes || aligned4(out.codes));
   if (channels == 1 && vec) {
     const int64_t n4 = n >> 2;
-    const int grid = blocks_for(n4, DLMCQ_BLOCK * FQ_U, FQ_MAX_BLOCKS);
-    hipLaunchKernelGGL((fq_tensor_kernel<FORM, FQ_U>), dim3(grid), dim3(DLMCQ_BLOCK), 0, st, x, out, scale, offset,
+    const int grid = blocks_for(n4, FQ_BLOCK * FQ_U, FQ_MAX_BLOCKS);
+    hipLaunchKernelGGL((fq_tensor_kernel<FORM, FQ_U>), dim3(grid), dim3(FQ_BLOCK), 0, st, x, out, scale, offset,
                        n, lo, hi, g);
     return launch_status();
   }
   const int64_t slab = channels * inner;
   if (channels > 1 && vec && (slab % 4 == 0) && slab < (1ll << 31)) {
-    constexpr int64_t CH = (int64_t)DLMCQ_BLOCK * FQ_U * 4;
+    constexpr int64_t CH = (int64_t)FQ_BLOCK * FQ_U * 4;
     ChanGeom gm;
     gm.slab = slab;
     gm.cps = (uint32_t)((slab + CH - 1) / CH);
@@ -332,10 +353,10 @@ static int launch_fq(const float* x, const FqOut& out, const float* scale, const
     if (rows > channels) rows = channels;
     const size_t lds = (size_t)rows * sizeof(float2);
     if (inner % 4 == 0)
-      hipLaunchKernelGGL((fq_channel_kernel<FORM, FQ_U, true>), dim3((uint32_t)blocks), dim3(DLMCQ_BLOCK), lds, st, x,
+      hipLaunchKernelGGL((fq_channel_kernel<FORM, FQ_U, true>), dim3((uint32_t)blocks), dim3(FQ_BLOCK), lds, st, x,
                          out, scale, offset, gm, lo, hi, g);
     else
-      hipLaunchKernelGGL((fq_channel_kernel<FORM, FQ_U, false>), dim3((uint32_t)blocks), dim3(DLMCQ_BLOCK), lds, st,
+      hipLaunchKernelGGL((fq_channel_kernel<FORM, FQ_U, false>), dim3((uint32_t)blocks), dim3(FQ_BLOCK), lds, st,
                          x, out, scale, offset, gm, lo, hi, g);
     return launch_status();
   }

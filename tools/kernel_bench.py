@@ -22,19 +22,24 @@ from dlmc.quantization.scalar import kernels as K  # noqa: E402
 PEAK = 8000.0  # GB/s, HBM3E spec
 
 
+REPS = 8  # launches per event pair: back-to-back, so host launch latency is hidden behind the GPU queue
+
+
 def timeit(fn, iters, warmup=3, flush=None):
     for _ in range(warmup):
         fn()
     ts = []
+    reps = 1 if flush is not None else REPS
     for _ in range(iters):
         if flush is not None:
             flush()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        fn()
+        for _ in range(reps):
+            fn()
         b.record()
         b.synchronize()
-        ts.append(a.elapsed_time(b) * 1e3)  # us
+        ts.append(a.elapsed_time(b) * 1e3 / reps)  # us per launch
     return statistics.median(ts), min(ts)
 
 
