@@ -54,14 +54,26 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(batch, budget_s=20.0):
+def cpu_baseline(batch, budget_s=20.0, fold_bn=True):
     """The reference's CPU path (port in oracle/ref_layers.py) on a bounded sample of the same workload."""
     import workloads as W
     from oracle.ref_layers import port_model
     cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(2333)
-    model = port_model(W.resnet50().eval(), "FSPTQ")
+    model = W.resnet50().eval()
+    if fold_bn:
+        from oracle import fakequant_oracle as O
+        for name, m in list(model.named_modules()):      # the same BN folding, by the oracle, on the CPU model
+            for cname, child in list(m.named_children()):
+                if isinstance(child, torch.nn.BatchNorm2d):
+                    target = cname.replace("bn", "conv") if not cname.isdecimal() else str(int(cname) - 1)
+                    conv = getattr(m, target)
+                    w, b = O.fold_bn(conv.weight.data, None if conv.bias is None else conv.bias.data, child.weight.data,
+                                     child.bias.data, child.running_mean, child.running_var)
+                    conv.weight.data, conv.bias = w, torch.nn.Parameter(b)
+                    setattr(m, cname, torch.nn.Identity())
+    model = port_model(model, "FSPTQ")
     x = torch.randn(batch, 3, 224, 224)
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -85,6 +97,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="images per GPU")
     ap.add_argument("--model", default="resnet50", choices=["resnet18", "resnet50", "repvgg_a1"])
+    ap.add_argument("--keep-bn", action="store_true",
+                    help="skip the BN folding of the reference's few-shot PTQ flow (FSPTQuant.py:67) and keep BatchNorm layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     args = ap.parse_args()
@@ -106,6 +120,9 @@ def main():
 
     torch.manual_seed(2333)  # the reference's seed; identical weights on every rank (replicated)
     model = W.MODELS[args.model]().to(dev).eval()
+    if not args.keep_bn:
+        from dlmc.utils.merge_bn import merge_bn
+        model = merge_bn(model, inplace=True, allow_missing=True)   # FSPTQuant.py:67: merge_bn, then quantize_model
     quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ")
     g = torch.Generator(device=dev).manual_seed(2333 + rank)
     x = torch.randn(args.batch, 3, 224, 224, device=dev, generator=g)
@@ -156,7 +173,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} W8A8 per-channel fake-quant forward (FSPTQ forms: W minmax_channel s8, "
-                               f"A minmax_tensor u8), 224x224, batch {args.batch} per GPU, scales frozen",
+                               f"A minmax_tensor u8), {'BatchNorm kept' if args.keep_bn else 'BN folded first as in FSPTQuant.py:67'}, "
+                               f"224x224, batch {args.batch} per GPU, scales frozen",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -172,7 +190,7 @@ def main():
                                     for k, f in fam.items() if f["ms"] > 0}},
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_batch, fold_bn=not args.keep_bn)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -102,6 +102,31 @@ class RepVGGDeployBlock(nn.Module):
         return self.nonlinearity(self.rbr_reparam(x))
 
 
+class RepVGGTrainBlock(nn.Module):
+    """A RepVGG block in its multi-branch training form (3x3+BN, 1x1+BN, identity BN), with the reference's
+    attribute names (repvgg.py:22-60) so `dlmc.utils.reparam` converts it."""
+
+    def __init__(self, cin, cout, stride, groups=1):
+        super().__init__()
+        self.in_channels, self.groups = cin, groups
+        self.rbr_identity = nn.BatchNorm2d(cin) if (cin == cout and stride == 1) else None
+
+        def conv_bn(k, pad):
+            seq = nn.Sequential()
+            seq.add_module("conv", nn.Conv2d(cin, cout, k, stride=stride, padding=pad, groups=groups, bias=False))
+            seq.add_module("bn", nn.BatchNorm2d(cout))
+            return seq
+        self.rbr_dense = conv_bn(3, 1)
+        self.rbr_1x1 = conv_bn(1, 0)
+        self.nonlinearity = nn.ReLU()
+
+    def forward(self, x):
+        if hasattr(self, "rbr_reparam"):
+            return self.nonlinearity(self.rbr_reparam(x))
+        idt = 0 if self.rbr_identity is None else self.rbr_identity(x)
+        return self.nonlinearity(self.rbr_dense(x) + self.rbr_1x1(x) + idt)
+
+
 class RepVGGDeploy(nn.Module):
     def __init__(self, num_blocks, widths, num_classes=1000):
         super().__init__()

@@ -179,6 +179,29 @@ int dlmcq_fake_quant_bwd_f32(const float* x, const float* gy, float* gx, float* 
 int dlmcq_rootq_weight_f32(const float* w, float* y, const float* bounds, int64_t n, int32_t lo,
                            int32_t hi, dlmcq_stream_t stream);
 
+/* ---- weight transforms that precede the path in the few-shot PTQ flow (FSPTQuant.py:65-67) ---- */
+
+/*
+ * BatchNorm folding, in place (dlmc/utils/merge_bn.py:85-101): with sd = sqrt(var + var_eps)
+ *   weight[k, :] <- (weight[k, :] * gamma[k]) / sd[k];   bias[k] <- (gamma[k]*(bias[k] - mean[k])) / sd[k] + beta[k]
+ * The reference adds 1e-7 to the running variance here (not the layer's eps): pass var_eps = 1e-7f.
+ * weight is [out_channels, inner]; bias must exist ([out_channels], zeros when the conv had none).
+ */
+int dlmcq_fold_bn_f32(float* weight, float* bias, const float* gamma, const float* beta,
+                      const float* mean, const float* var, int64_t out_channels, int64_t inner,
+                      float var_eps, dlmcq_stream_t stream);
+
+/*
+ * RepVGG re-parameterisation (model/classification/repvgg.py:92-147): the 3x3 branch, the 1x1 branch and
+ * the optional identity branch, each followed by BatchNorm, fused into one 3x3 kernel + bias.
+ * bn3 / bn1 / bnid are HOST arrays of 4 device pointers {gamma, beta, running_mean, running_var}; bnid is
+ * NULL when the block has no identity branch.  k3 is [K, cin_per_group, 3, 3], k1 is [K, cin_per_group, 1, 1].
+ */
+int dlmcq_repvgg_fuse_f32(const float* k3, const float* k1, float* out_kernel, float* out_bias,
+                          const float* const* bn3, const float* const* bn1, const float* const* bnid,
+                          float eps3, float eps1, float epsid, int64_t out_channels,
+                          int64_t cin_per_group, dlmcq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

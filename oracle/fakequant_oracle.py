@@ -315,3 +315,35 @@ def fsptq_layer_forward(layer, x, in_scale, in_zp, wt_scale, in_rng, wt_rng):
     _, xq = fq_zeropoint(x, in_scale, in_zp, in_rng[0], in_rng[1])
     _, wq = fq_symmetric(layer.weight.detach(), wt_scale, wt_rng[0], wt_rng[1])
     return xq, wq, conv_or_linear(layer, xq, wq)
+
+
+# ------------------------------------------------- weight transforms that precede the path
+def fold_bn(weight, bias, gamma, beta, mean, var):
+    """dlmc/utils/merge_bn.py:85-101: note var + 1e-7 (not bn.eps).  Returns (weight', bias')."""
+    v = var + 1e-7
+    cout = weight.shape[0]
+    if bias is None or bias.numel() == 0:
+        bias = torch.zeros(cout)
+    b = gamma * (bias - mean) / v.sqrt() + beta
+    w = (weight.reshape(cout, -1) * gamma.reshape(-1, 1) / v.sqrt().reshape(-1, 1)).reshape(weight.shape)
+    return w, b
+
+
+def repvgg_fuse(k3, bn3, k1, bn1, bnid, groups=1):
+    """model/classification/repvgg.py:92-130.  bn* = (gamma, beta, mean, var, eps); bnid may be None."""
+    def branch(kernel, bn):
+        gamma, beta, mean, var, eps = bn
+        std = (var + eps).sqrt()
+        return kernel * (gamma / std).reshape(-1, 1, 1, 1), beta - mean * gamma / std
+    ka, ba = branch(k3, bn3)
+    kb, bb = branch(k1, bn1)
+    kb = torch.nn.functional.pad(kb, [1, 1, 1, 1])
+    if bnid is None:
+        return ka + kb + 0, ba + bb + 0
+    cin = k3.shape[0]
+    cg = cin // groups
+    ident = torch.zeros(cin, cg, 3, 3)
+    for i in range(cin):
+        ident[i, i % cg, 1, 1] = 1
+    kc, bc = branch(ident, bnid)
+    return ka + kb + kc, ba + bb + bc

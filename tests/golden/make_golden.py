@@ -483,6 +483,74 @@ def case_estimators():
             idx += 1
 
 
+# ------------------------------------------------------- weight transforms before the path
+def case_weight_transforms():
+    """dlmc/utils/merge_bn.py:45-113 and model/classification/repvgg.py:92-147 (switch_to_deploy)."""
+    # merge_bn imports the BitMixer package, which is missing from the reference: give it a shell
+    bm = types.ModuleType("dlmc.quantization.scalar.BitMixer")
+    bm.BitMixerBatchNorm = bm.BitMixerSwitchableBatchNorm = type("Missing", (), {})
+    sys.modules["dlmc.quantization.scalar.BitMixer"] = bm
+    spec = importlib.util.spec_from_file_location("ref_access", os.path.join(REF, "dlmc/utils/access.py"))
+    # dlmc/utils/__init__ pulls quantize.py (timm etc.): load merge_bn.py by path inside a package shell
+    pkg = types.ModuleType("dlmc.utils")
+    pkg.__path__ = [os.path.join(REF, "dlmc/utils")]
+    sys.modules["dlmc.utils"] = pkg
+    for sub in ("access", "merge_bn"):
+        sp = importlib.util.spec_from_file_location(f"dlmc.utils.{sub}", os.path.join(REF, f"dlmc/utils/{sub}.py"))
+        m = importlib.util.module_from_spec(sp)
+        sys.modules[f"dlmc.utils.{sub}"] = m
+        sp.loader.exec_module(m)
+    ref_merge = sys.modules["dlmc.utils.merge_bn"]
+    sp = importlib.util.spec_from_file_location("ref_repvgg", os.path.join(REF, "model/classification/repvgg.py"))
+    ref_repvgg = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(ref_repvgg)
+    import contextlib, io
+
+    def randomise_bn(bn, g):
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(bn.num_features, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(bn.num_features, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(bn.num_features, generator=g) * 0.2)
+            bn.running_var.copy_(torch.rand(bn.num_features, generator=g) + 0.3)
+
+    for j, (bias, groups) in enumerate(((False, 1), (True, 1), (True, 2))):
+        g = gen(6000 + j)
+        net = torch.nn.Sequential()
+        net.add_module("conv1", torch.nn.Conv2d(4, 6, 3, padding=1, bias=bias, groups=groups))
+        net.add_module("bn1", torch.nn.BatchNorm2d(6))
+        with torch.no_grad():
+            net.conv1.weight.copy_(torch.randn(net.conv1.weight.shape, generator=g) * 0.3)
+            if bias:
+                net.conv1.bias.copy_(torch.randn(6, generator=g) * 0.1)
+        randomise_bn(net.bn1, g)
+        pre = {k: v.clone() for k, v in net.state_dict().items()}
+        merged = ref_merge.merge_bn(net, inplace=True)
+        name = f"mergebn{j}"
+        put(name, weight=pre["conv1.weight"], bias=pre.get("conv1.bias", torch.zeros(0)), gamma=pre["bn1.weight"],
+            beta=pre["bn1.bias"], mean=pre["bn1.running_mean"], var=pre["bn1.running_var"],
+            out_weight=merged.conv1.weight, out_bias=merged.conv1.bias)
+        CASES.append(dict(name=name, kind="merge_bn", groups=groups, has_bias=bias,
+                          bn_replaced_by=type(merged.bn1).__name__))
+    for j, (cin, cout, stride, groups) in enumerate(((8, 8, 1, 1), (8, 12, 2, 1), (8, 8, 1, 2), (6, 6, 2, 1))):
+        g = gen(6100 + j)
+        with contextlib.redirect_stdout(io.StringIO()):
+            blk = ref_repvgg.RepVGGBlock(cin, cout, 3, stride=stride, padding=1, groups=groups)
+        with torch.no_grad():
+            blk.rbr_dense.conv.weight.copy_(torch.randn(blk.rbr_dense.conv.weight.shape, generator=g) * 0.2)
+            blk.rbr_1x1.conv.weight.copy_(torch.randn(blk.rbr_1x1.conv.weight.shape, generator=g) * 0.2)
+        for bn in (blk.rbr_dense.bn, blk.rbr_1x1.bn, blk.rbr_identity):
+            if bn is not None:
+                randomise_bn(bn, g)
+        pre = {k: v.clone() for k, v in blk.state_dict().items()}
+        blk.eval()
+        blk.switch_to_deploy()
+        name = f"repvgg{j}"
+        put(name, out_kernel=blk.rbr_reparam.weight, out_bias=blk.rbr_reparam.bias,
+            **{("pre_" + k.replace(".", "__")): v for k, v in pre.items() if "num_batches" not in k})
+        CASES.append(dict(name=name, kind="repvgg", cin=cin, cout=cout, stride=stride, groups=groups,
+                          has_identity=any(k.startswith("rbr_identity") for k in pre)))
+
+
 def main():
     torch.manual_seed(SEED)
     torch.set_num_threads(1)
@@ -492,6 +560,7 @@ def main():
     case_fsptq()
     case_rootq()
     case_estimators()
+    case_weight_transforms()
     np.savez_compressed(os.path.join(HERE, "golden_v1.npz"), **ARR)
     with open(os.path.join(HERE, "golden_v1.json"), "w") as f:
         json.dump(dict(seed=SEED, torch=torch.__version__, cases=CASES), f, indent=1, default=str)

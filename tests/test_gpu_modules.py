@@ -331,3 +331,48 @@ def test_resnet18_config1_end_to_end():
         assert_bits_equal(caps[n].weight, want_w, n + ".fq_weight")
     for h in hooks:
         h.remove()
+
+
+def test_merge_bn_and_repvgg_reparam(golden):
+    """The two weight transforms that precede quantize_model in the RepAPQ flow (FSPTQuant.py:65-67)."""
+    import workloads as W
+    from dlmc.utils.merge_bn import DEFAULT_BN_MAPPING_FN, DEFAULT_CONV_MAPPING_FN, merge_bn
+    from dlmc.utils.reparam import repvgg_model_convert
+    assert DEFAULT_CONV_MAPPING_FN("layer1.conv1.1") == "layer1.conv1.0" and DEFAULT_CONV_MAPPING_FN("layer1.bn1") == "layer1.conv1"
+    assert DEFAULT_BN_MAPPING_FN("layer1.conv1.0") == "layer1.conv1.1" and DEFAULT_BN_MAPPING_FN("fc") is None
+    for c in golden.of_kind("merge_bn"):
+        net = nn.Sequential()
+        net.add_module("conv1", nn.Conv2d(4, 6, 3, padding=1, bias=c["has_bias"], groups=c["groups"]))
+        net.add_module("bn1", nn.BatchNorm2d(6))
+        with torch.no_grad():
+            net.conv1.weight.copy_(golden.get(c, "weight"))
+            if c["has_bias"]:
+                net.conv1.bias.copy_(golden.get(c, "bias"))
+            for dst, key in ((net.bn1.weight, "gamma"), (net.bn1.bias, "beta"), (net.bn1.running_mean, "mean"),
+                             (net.bn1.running_var, "var")):
+                dst.copy_(golden.get(c, key))
+        net = net.to(DEV).eval()
+        x = torch.randn(2, 4, 8, 8, device=DEV)
+        with torch.no_grad():
+            ref = net(x)
+            merged = merge_bn(net, inplace=True)
+            assert isinstance(merged.bn1, nn.Identity) and isinstance(net.bn1, nn.BatchNorm2d)  # a deep copy was merged
+            assert_bits_equal(merged.conv1.weight, golden.get(c, "out_weight"), c["name"] + ".weight")
+            assert_bits_equal(merged.conv1.bias, golden.get(c, "out_bias"), c["name"] + ".bias")
+            close(merged(x), ref, c["name"] + " output", rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError):
+        merge_bn(nn.Sequential(nn.BatchNorm2d(3)).to(DEV))
+    for c in golden.of_kind("repvgg"):
+        blk = W.RepVGGTrainBlock(c["cin"], c["cout"], c["stride"], c["groups"])
+        sd = {k[4:].replace("__", "."): golden.get(c, k) for k in
+              [f.split(".", 1)[1] for f in golden.arr.files if f.startswith(c["name"] + ".pre_")]}
+        blk.load_state_dict(sd, strict=False)
+        blk = blk.to(DEV).eval()
+        x = torch.randn(2, c["cin"], 8, 8, device=DEV)
+        with torch.no_grad():
+            ref = blk(x)
+            dep = repvgg_model_convert(blk)
+            assert hasattr(dep, "rbr_reparam") and not hasattr(dep, "rbr_dense") and hasattr(blk, "rbr_dense")
+            assert_bits_equal(dep.rbr_reparam.weight, golden.get(c, "out_kernel"), c["name"] + ".kernel")
+            assert_bits_equal(dep.rbr_reparam.bias, golden.get(c, "out_bias"), c["name"] + ".bias")
+            close(dep(x), ref, c["name"] + " output", rtol=1e-4, atol=1e-4)

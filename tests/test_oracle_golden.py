@@ -241,3 +241,21 @@ def test_estimators(golden):
             s, o = O.l2loss_channel(x, c["n_bits"], c["signed"], ch_axis=c["ch_axis"])
             assert_bits_equal(s, golden.get(c, "l2loss_c_scale"))
             assert_bits_equal(o, golden.get(c, "l2loss_c_offset"))
+
+
+def test_weight_transforms(golden):
+    for c in golden.of_kind("merge_bn"):
+        b = golden.get(c, "bias")
+        w, bo = O.fold_bn(golden.get(c, "weight"), b if b.numel() else None, golden.get(c, "gamma"), golden.get(c, "beta"),
+                          golden.get(c, "mean"), golden.get(c, "var"))
+        assert_bits_equal(w, golden.get(c, "out_weight"), c["name"] + ".weight")
+        assert_bits_equal(bo, golden.get(c, "out_bias"), c["name"] + ".bias")
+        assert c["bn_replaced_by"] == "Identity"
+    for c in golden.of_kind("repvgg"):
+        def bn(prefix, eps=1e-5):
+            return tuple(golden.get(c, f"pre_{prefix}__{k}") for k in ("weight", "bias", "running_mean", "running_var")) + (eps,)
+        k, b = O.repvgg_fuse(golden.get(c, "pre_rbr_dense__conv__weight"), bn("rbr_dense__bn"),
+                             golden.get(c, "pre_rbr_1x1__conv__weight"), bn("rbr_1x1__bn"),
+                             bn("rbr_identity") if c["has_identity"] else None, groups=c["groups"])
+        assert_bits_equal(k, golden.get(c, "out_kernel"), c["name"] + ".kernel")
+        assert_bits_equal(b, golden.get(c, "out_bias"), c["name"] + ".bias")
