@@ -359,7 +359,7 @@ def test_merge_bn_and_repvgg_reparam(golden):
             assert isinstance(merged.bn1, nn.Identity) and isinstance(net.bn1, nn.BatchNorm2d)  # a deep copy was merged
             assert_bits_equal(merged.conv1.weight, golden.get(c, "out_weight"), c["name"] + ".weight")
             assert_bits_equal(merged.conv1.bias, golden.get(c, "out_bias"), c["name"] + ".bias")
-            close(merged(x), ref, c["name"] + " output", rtol=1e-4, atol=1e-4)
+            close(merged(x), ref.cpu(), c["name"] + " output", rtol=1e-4, atol=1e-4)
     with pytest.raises(ValueError):
         merge_bn(nn.Sequential(nn.BatchNorm2d(3)).to(DEV))
     for c in golden.of_kind("repvgg"):
@@ -375,4 +375,4 @@ def test_merge_bn_and_repvgg_reparam(golden):
             assert hasattr(dep, "rbr_reparam") and not hasattr(dep, "rbr_dense") and hasattr(blk, "rbr_dense")
             assert_bits_equal(dep.rbr_reparam.weight, golden.get(c, "out_kernel"), c["name"] + ".kernel")
             assert_bits_equal(dep.rbr_reparam.bias, golden.get(c, "out_bias"), c["name"] + ".bias")
-            close(dep(x), ref, c["name"] + " output", rtol=1e-4, atol=1e-4)
+            close(dep(x), ref.cpu(), c["name"] + " output", rtol=1e-4, atol=1e-4)
