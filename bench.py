@@ -99,9 +99,13 @@ def main():
     ap.add_argument("--model", default="resnet50", choices=["resnet18", "resnet50", "repvgg_a1"])
     ap.add_argument("--keep-bn", action="store_true",
                     help="skip the BN folding of the reference's few-shot PTQ flow (FSPTQuant.py:67) and keep BatchNorm layers")
+    ap.add_argument("--conv", choices=["int8", "fp32"], default="int8",
+                    help="int8 (default): fused int8-dequant x GEMM convs/linears on the matrix cores - BASELINE configs[2] names "
+                         "this path; fp32: MIOpen fp32 conv of the fake-quantised operands (the reference's own op sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     args = ap.parse_args()
+    args.int8 = args.conv == "int8"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -123,9 +127,11 @@ def main():
     if not args.keep_bn:
         from dlmc.utils.merge_bn import merge_bn
         model = merge_bn(model, inplace=True, allow_missing=True)   # FSPTQuant.py:67: merge_bn, then quantize_model
-    quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ")
+    quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=args.int8)
     g = torch.Generator(device=dev).manual_seed(2333 + rank)
     x = torch.randn(args.batch, 3, 224, 224, device=dev, generator=g)
+    if args.int8:
+        x = x.contiguous(memory_format=torch.channels_last)   # activations travel NHWC for the matrix cores
 
     def barrier():
         if world > 1:
@@ -174,6 +180,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} W8A8 per-channel fake-quant forward (FSPTQ forms: W minmax_channel s8, "
                                f"A minmax_tensor u8), {'BatchNorm kept' if args.keep_bn else 'BN folded first as in FSPTQuant.py:67'}, "
+                               f"{'fused int8 MFMA conv/linear' if args.int8 else 'fp32 conv of the fake-quantised operands'}, "
                                f"224x224, batch {args.batch} per GPU, scales frozen",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -189,6 +196,17 @@ def main():
                        "families": {k: {"launches": f["launches"], "GBps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)}
                                     for k, f in fam.items() if f["ms"] > 0}},
     }
+    cv = fam.get("conv_i8")
+    if cv and cv["ms"] > 0:
+        import workloads as W2
+        macs = sum(r[4] for r in W2.layer_table(W2.MODELS[args.model](), torch.zeros(1, 3, 224, 224))
+                   if r[3][1] % 64 == 0)   # the layers eligible for the int8 path (input channels % 64 == 0)
+        out["conv_i8"] = {"bound": "hbm at these shapes (fp32 outputs: 4 B written per output element vs 1 B read per input element); "
+                                   "mfma for the 3x3 layers",
+                          "launches": cv["launches"], "ms_per_step": round(cv["ms"] / args.steps, 3),
+                          "GBps": round(cv["bytes"] / (cv["ms"] * 1e-3) / 1e9, 1),
+                          "TOPs": round(2 * macs * args.batch * args.steps / (cv["ms"] * 1e-3) / 1e12, 1),
+                          "peak_TOPs_dense_i8": 5000.0}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_batch, fold_bn=not args.keep_bn)
     print(json.dumps(out), flush=True)

@@ -1,0 +1,240 @@
+// Fused int8-dequant x GEMM convolution / linear on the gfx950 matrix cores (the quantised
+// conv/linear of modules/conv.py:13-19, modules/linear.py:12-13 where it really is a dense contraction).
+//
+// Reference semantics:  out = conv(x', w') + bias  with  x' = (q - zp) * s_in   (FSPTQuant/base.py:108-109)
+//                                                        w' = qw * s_w[k]       (FSPTQuant/base.py:149-152)
+// computed here as      out = s_in * s_w[k] * ( SUM q'*qw  +  (shift - zp) * SUM qw )  + bias[k]
+// with q' = q - shift the int8 operand (shift = 128 for uint8 codes, 0 for int8 codes), exact int32
+// accumulation on v_mfma_i32_32x32x32_i8, ONE rounding chain at the end.  Padded taps contribute x' = 0,
+// i.e. q = zp, so out-of-bounds operand bytes are filled with (zp - shift) and SUM qw runs over all taps.
+//
+// Layouts (chosen for the matrix cores; torch sees them as channels_last tensors, no copy):
+//   activations  int8  NHWC   - for a fixed tap the 64 reduction bytes of a BK step are contiguous
+//   weights      int8  KRSC   - same reduction order (r, s, c), produced by quantize_weight_krsc_kernel
+//   output       fp32  NHWC   - lanes of an accumulator register hold 32 consecutive channels: 128-B stores
+// Implicit GEMM: M = N*P*Q output pixels, N = K output channels, K = R*S*C.  At ResNet sizes with fp32 outputs
+// this kernel is HBM-bound (4 B written per MAC-row vs 1 B read), so the structure favours streaming: BM = 128
+// pixels x BN in {64, 128} channels per workgroup, 4 waves (one 32-row slab each), BK = 64, double-buffered LDS
+// with register staging (one barrier per K step), rows padded to 80 B so ds_read_b128 fragments are conflict-free.
+#include "dlmcq_internal.h"
+
+namespace dlmcq {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CV_BM = 128;
+constexpr int CV_BK = 64;
+constexpr int CV_LD = CV_BK + 16;  // LDS row stride in bytes
+
+struct ConvGeom {
+  int N, H, W, C, K, R, S, stride, pad, dil, P, Q;
+  int64_t M;          // N*P*Q
+  int nblk_m, nblk_n;
+};
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                     float* __restrict__ out, const float* __restrict__ bias,
+                                                     const int32_t* __restrict__ wsum, const float* __restrict__ s_in,
+                                                     const float* __restrict__ zp_in, const float* __restrict__ s_w,
+                                                     ConvGeom g, int shift) {
+  __shared__ __attribute__((aligned(16))) int8_t lds[2 * (CV_BM + BN) * CV_LD];
+  int8_t* ldsA = lds;
+  int8_t* ldsB = lds + 2 * CV_BM * CV_LD;
+  constexpr int NT = BN / 32;          // 32x32 output tiles per wave along N
+  constexpr int BLOADS = BN / 64;      // 16-B weight loads per thread per K step
+
+  // XCD-aware tile order: the workgroups that share an activation tile (same m-block, different n-blocks)
+  // are consecutive in `tile`, and consecutive tiles are dealt to the SAME XCD (its L2 then serves the re-reads).
+  const uint32_t nwg = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t qd = nwg >> 3, rm = nwg & 7u;
+  const uint32_t tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
+  const int bn = tile % g.nblk_n, bm = tile / g.nblk_n;
+  const int64_t m0 = (int64_t)bm * CV_BM;
+  const int n0 = bn * BN;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float zpf = zp_in ? zp_in[0] : 0.0f;
+  const int zpi = (int)__builtin_rintf(zpf);
+  const uint32_t padw = (uint32_t)(uint8_t)(int8_t)(zpi - shift) * 0x01010101u;
+  const uint32_t xorw = shift ? 0x80808080u : 0u;   // uint8 code -> int8 operand: q - 128 == q ^ 0x80
+
+  // ---- staging assignment: thread -> (row, 16-byte segment) ----
+  const int seg = tid & 3, srow = tid >> 2;       // rows srow and srow + 64 of the A tile
+  int a_n[2], a_h0[2], a_w0[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t m = m0 + srow + 64 * i;
+    a_ok[i] = m < g.M;
+    const int64_t mm = a_ok[i] ? m : 0;
+    const int q = (int)(mm % g.Q);
+    const int64_t t = mm / g.Q;
+    const int p = (int)(t % g.P);
+    a_n[i] = (int)(t / g.P);
+    a_h0[i] = p * g.stride - g.pad;
+    a_w0[i] = q * g.stride - g.pad;
+  }
+  const int cchunks = g.C / CV_BK;
+  const int nsteps = g.R * g.S * cchunks;
+  const int64_t wrow = (int64_t)g.R * g.S * g.C;  // bytes per output channel in KRSC
+
+  i32x4 ra[2], rb[BLOADS];
+  auto fetch = [&](int step) {
+    const int cc = step % cchunks;
+    const int rs = step / cchunks;
+    const int s = rs % g.S, r = rs / g.S;
+    const int c0 = cc * CV_BK + seg * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int h = a_h0[i] + r * g.dil, ww = a_w0[i] + s * g.dil;
+      if (a_ok[i] && h >= 0 && h < g.H && ww >= 0 && ww < g.W) {
+        const int64_t off = (((int64_t)a_n[i] * g.H + h) * g.W + ww) * g.C + c0;
+        i32x4 v = *reinterpret_cast<const i32x4*>(x + off);
+        ra[i] = i32x4{(int)(v.x ^ xorw), (int)(v.y ^ xorw), (int)(v.z ^ xorw), (int)(v.w ^ xorw)};
+      } else {
+        ra[i] = i32x4{(int)padw, (int)padw, (int)padw, (int)padw};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BLOADS; ++i) {
+      const int k = n0 + srow + 64 * i;
+      if (k < g.K)
+        rb[i] = *reinterpret_cast<const i32x4*>(w + (int64_t)k * wrow + (int64_t)rs * g.C + c0);
+      else
+        rb[i] = i32x4{0, 0, 0, 0};
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<i32x4*>(ldsA + (buf * CV_BM + srow + 64 * i) * CV_LD + seg * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BLOADS; ++i)
+      *reinterpret_cast<i32x4*>(ldsB + (buf * BN + srow + 64 * i) * CV_LD + seg * 16) = rb[i];
+  };
+
+  i32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0;
+
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  const int arow = wave * 32 + (lane & 31), kq = (lane >> 5) * 16;
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) fetch(step + 1);       // global loads in flight under the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < CV_BK / 32; ++ks) {
+      const i32x4 af = *reinterpret_cast<const i32x4*>(ldsA + (buf * CV_BM + arow) * CV_LD + ks * 32 + kq);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const i32x4 bf = *reinterpret_cast<const i32x4*>(ldsB + (buf * BN + j * 32 + (lane & 31)) * CV_LD + ks * 32 + kq);
+        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[j], 0, 0, 0);
+      }
+    }
+    if (step + 1 < nsteps) stage(buf ^ 1);        // the other buffer was last read before the previous barrier
+    __syncthreads();
+  }
+
+  // ---- epilogue: one rounding chain; lanes 0-31 of a register hold 32 consecutive output channels ----
+  const float sin = s_in[0];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + j * 32 + (lane & 31);
+    if (col >= g.K) continue;
+    const float mult = sin * s_w[col];
+    const int corr = (shift - zpi) * wsum[col];
+    const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t row = m0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      if (row < g.M) out[row * g.K + col] = (float)(acc[j][i] + corr) * mult + bv;
+    }
+  }
+}
+
+// Weights fp32 KCRS -> int8 KRSC codes (form SYMMETRIC, FSPTQuant/base.py:149-152: q = clamp(R(w/s_k), lo, hi))
+// plus SUM_k = sum of the codes of output channel k.  One workgroup per output channel.
+__global__ __launch_bounds__(DLMCQ_BLOCK) void quantize_weight_krsc_kernel(const float* __restrict__ w, int8_t* __restrict__ wq,
+                                                                          int32_t* __restrict__ wsum,
+                                                                          const float* __restrict__ scale, int C, int RS,
+                                                                          float lo, float hi) {
+  __shared__ int part[DLMCQ_BLOCK / DLMCQ_WAVE];
+  const int64_t k = blockIdx.x;
+  const float s = scale[k];
+  const int n = C * RS;
+  int acc = 0;
+  for (int i = threadIdx.x; i < n; i += DLMCQ_BLOCK) {
+    const int c = i / RS, rs = i - c * RS;                    // input order (c, r, s)
+    const float q = clamp_nan(ste_round(w[k * n + i] / s), lo, hi);
+    const int code = code_of(q);
+    wq[k * n + (int64_t)rs * C + c] = (int8_t)code;           // output order (r, s, c)
+    acc += code;
+  }
+#pragma unroll
+  for (int off = DLMCQ_WAVE / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, DLMCQ_WAVE);
+  if ((threadIdx.x & (DLMCQ_WAVE - 1)) == 0) part[threadIdx.x / DLMCQ_WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) wsum[k] = part[0] + part[1] + part[2] + part[3];
+}
+
+}  // namespace dlmcq
+
+using namespace dlmcq;
+
+extern "C" int dlmcq_quantize_weight_krsc_i8(const float* w, int8_t* wq, int32_t* wsum, const float* scale,
+                                             int64_t K, int64_t C, int64_t R, int64_t S, int32_t lo, int32_t hi,
+                                             dlmcq_stream_t stream) {
+  if (K < 0 || C < 1 || R < 1 || S < 1 || lo > hi || lo < -128 || hi > 127) return DLMCQ_EINVAL;
+  if (K == 0) return DLMCQ_OK;
+  if (!w || !wq || !wsum || !scale) return DLMCQ_EINVAL;
+  if (K >= (1ll << 31) || C * R * S >= (1ll << 31)) return DLMCQ_ERANGE;
+  hipLaunchKernelGGL(quantize_weight_krsc_kernel, dim3((uint32_t)K), dim3(DLMCQ_BLOCK), 0,
+                     reinterpret_cast<hipStream_t>(stream), w, wq, wsum, scale, (int)C, (int)(R * S), (float)lo, (float)hi);
+  return launch_status();
+}
+
+extern "C" int dlmcq_conv2d_i8_nhwc_f32(const void* x, const int8_t* w, float* out, const float* bias,
+                                        const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                                        const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
+                                        int64_t R, int64_t S, int32_t stride, int32_t pad, int32_t dilation,
+                                        int32_t x_is_unsigned, dlmcq_stream_t stream) {
+  if (N < 0 || H < 1 || W < 1 || C < 1 || K < 1 || R < 1 || S < 1 || stride < 1 || pad < 0 || dilation < 1)
+    return DLMCQ_EINVAL;
+  if (C % CV_BK != 0) return DLMCQ_EINVAL;  // the K step is 64 input channels
+  const int64_t P = (H + 2 * pad - dilation * (R - 1) - 1) / stride + 1;
+  const int64_t Q = (W + 2 * pad - dilation * (S - 1) - 1) / stride + 1;
+  if (P < 1 || Q < 1) return DLMCQ_EINVAL;
+  const int64_t M = N * P * Q;
+  if (M == 0) return DLMCQ_OK;
+  if (!x || !w || !out || !wsum || !in_scale || !w_scale) return DLMCQ_EINVAL;
+  if (!aligned16(x) || !aligned16(w)) return DLMCQ_EALIGN;
+  if (M >= (1ll << 31) || N * H * W * C >= (1ll << 40) || K >= (1 << 24)) return DLMCQ_ERANGE;
+  ConvGeom g;
+  g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C = (int)C; g.K = (int)K; g.R = (int)R; g.S = (int)S;
+  g.stride = stride; g.pad = pad; g.dil = dilation; g.P = (int)P; g.Q = (int)Q; g.M = M;
+  g.nblk_m = (int)((M + CV_BM - 1) / CV_BM);
+  const int shift = x_is_unsigned ? 128 : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int8_t* xs = reinterpret_cast<const int8_t*>(x);
+  if (K <= 64 || (K % 128) != 0) {
+    g.nblk_n = (int)((K + 63) / 64);
+    const int64_t nwg = (int64_t)g.nblk_m * g.nblk_n;
+    if (nwg >= (1ll << 31)) return DLMCQ_ERANGE;
+    hipLaunchKernelGGL((conv_i8_kernel<64>), dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale,
+                       in_zero_point, w_scale, g, shift);
+  } else {
+    g.nblk_n = (int)(K / 128);
+    const int64_t nwg = (int64_t)g.nblk_m * g.nblk_n;
+    if (nwg >= (1ll << 31)) return DLMCQ_ERANGE;
+    hipLaunchKernelGGL((conv_i8_kernel<128>), dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale,
+                       in_zero_point, w_scale, g, shift);
+  }
+  return launch_status();
+}

@@ -17,7 +17,7 @@ from torch.nn import Module
 
 from .... import _native as N
 from .. import ops
-from .._wrapper import InitState, fake_quant, set_scale
+from .._wrapper import InitState, fake_quant, int8_forward, int8_gemm_default, int8_layer_ok, set_scale
 from ..utils import get_qrange
 
 
@@ -52,6 +52,24 @@ class FSPTQBase(Module):
             self.gamma, self.zeta = -0.1, 1.1
             self.beta = 2 / 3
         self._init = InitState()
+        # fused int8 conv/linear on the matrix cores: opt-in (qconfig["int8_gemm"] or DLMC_INT8_GEMM=1); the
+        # default is the reference-identical fp32 conv of the fake-quantised operands
+        self.int8_gemm = bool(qconfig.get("int8_gemm", int8_gemm_default()))
+        self._zp_is_int = None
+
+    def _int8_applicable(self, input):
+        if not (self.int8_gemm and self.act_quant and self.wt_quant) or torch.is_grad_enabled():
+            return False
+        if self.qconfig["weight"].get("recon_type") in ("adaround", "dist_recon") or self.in_scale.numel() != 1:
+            return False
+        if not (int8_layer_ok(self) and self.wt_min_val >= -128 and self.wt_max_val <= 127):
+            return False
+        if not (0 <= self.in_min_val and self.in_max_val <= 255) and not (-128 <= self.in_min_val and self.in_max_val <= 127):
+            return False
+        if self._zp_is_int is None:   # one host read, right after calibration
+            zp = float(self.in_offset.reshape(-1)[0])
+            self._zp_is_int = zp == round(zp) and self.in_min_val <= zp <= self.in_max_val
+        return self._zp_is_int
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         key = prefix + "in_offset"   # becomes 0-dim after calibration (base.py:99)
@@ -59,6 +77,7 @@ class FSPTQBase(Module):
             self.in_offset = torch.zeros_like(state_dict[key], dtype=torch.float32, device=self.weight.device)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
         self._init.invalidate()
+        self._zp_is_int = None
 
     def _forward_func(self, input, weight):
         raise NotImplementedError
@@ -93,6 +112,7 @@ class FSPTQBase(Module):
         scale, offset = ops.get_qparams_tensor(input.detach(), qtype=cfg["type"], **kw)
         set_scale(self.in_scale, scale)
         self.in_offset = offset.detach().to(torch.float32)
+        self._zp_is_int = None
         self._init.mark(self, "in_init_state")
 
     def _calibrate_weight(self):
@@ -107,15 +127,18 @@ class FSPTQBase(Module):
     def forward(self, input):
         N.require_gpu(input, self.weight)
         q_input = input
+        if self.act_quant and not self._init.ready(self, "in_init_state"):
+            self._calibrate_input(input)
+        if self.wt_quant and not self._init.ready(self, "wt_init_state"):
+            self._calibrate_weight()
+        if self._int8_applicable(input):
+            return int8_forward(self, input, self.in_scale, self.in_offset, self.in_min_val, self.in_max_val,
+                                N.FORM_ZEROPOINT, self.wt_scale, self.wt_min_val, self.wt_max_val)
         if self.act_quant:
-            if not self._init.ready(self, "in_init_state"):
-                self._calibrate_input(input)
             q_input = fake_quant(input, self.in_scale, self.in_offset, self.in_min_val, self.in_max_val,
                                  N.FORM_ZEROPOINT)
         if not self.wt_quant:
             return self._forward_func(q_input, self.weight)
-        if not self._init.ready(self, "wt_init_state"):
-            self._calibrate_weight()
         recon = self.qconfig["weight"].get("recon_type")
         if recon == "adaround":
             # block-reconstruction training: alpha is learnable, so this stays a differentiable device

@@ -155,6 +155,39 @@ def observe_minmax(x, n_bits, signed, ch_axis=None, allow_offset=True, scale_eps
     return s.reshape(shape), o.reshape(shape)
 
 
+# ------------------------------------------------------ fused int8 conv / linear (matrix cores)
+def int8_gemm_default():
+    return os.environ.get("DLMC_INT8_GEMM", "0") == "1"
+
+
+def int8_layer_ok(mod):
+    """Static eligibility of a layer for the fused int8 path (dlmcq_conv2d_i8_nhwc_f32): dense (groups = 1)
+    zero-padded conv with square stride/padding/dilation, or a linear layer; input channels a multiple of 64."""
+    w = mod.weight
+    if w.dim() == 2:
+        return w.shape[1] % 64 == 0
+    if w.dim() != 4 or mod.groups != 1 or mod.padding_mode != "zeros" or isinstance(mod.padding, str):
+        return False
+    sq = lambda t: len(set(t)) == 1  # noqa: E731
+    return w.shape[1] % 64 == 0 and sq(mod.stride) and sq(mod.padding) and sq(mod.dilation)
+
+
+def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, wt_lo, wt_hi):
+    """Quantise the activation to integer codes (one pass, 4 B read + 1 B written per element), quantise the
+    weight to KRSC int8, and contract on v_mfma_i32_32x32x32_i8 with the dequantisation fused into the epilogue.
+    Same mathematical result as F.conv2d(fake_quant(x), fake_quant(w), bias); activations travel channels_last."""
+    if input.dim() == 4 and not input.is_contiguous(memory_format=torch.channels_last):
+        input = input.contiguous(memory_format=torch.channels_last)   # one transposing copy, at the model's first int8 layer
+    _, codes = K.fake_quant(input, in_scale.detach(), in_zp, in_lo, in_hi, act_form, codes="i8", want_y=False)
+    wq, wsum = K.quantize_weight_krsc(mod.weight, wt_scale, wt_lo, wt_hi)
+    if mod.weight.dim() == 2:
+        flat = codes.reshape(-1, codes.shape[-1])
+        out = K.conv2d_i8(flat, wq, wsum, mod.bias, in_scale, in_zp, wt_scale)
+        return out.reshape(*codes.shape[:-1], out.shape[-1])
+    return K.conv2d_i8(codes, wq, wsum, mod.bias, in_scale, in_zp, wt_scale, stride=mod.stride[0],
+                       padding=mod.padding[0], dilation=mod.dilation[0])
+
+
 # ------------------------------------------------------------------- init-state bookkeeping
 class InitState:
     """Host mirror of the `in_init_state` / `wt_init_state` buffers.  The buffer stays the source of

@@ -13,7 +13,7 @@ from ..._native import (CODES_I8, CODES_NONE, CODES_P4, FORM_EMULATE, FORM_QBASE
                         Y_CODES, Y_DEQUANT)
 
 __all__ = ["fake_quant", "dequant_codes", "dequant", "minmax", "observe_qparams", "qparams_from_minmax",
-           "span_scale", "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
+           "span_scale", "quantize_weight_krsc", "conv2d_i8", "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
            "PROFILE"]
 
 
@@ -79,12 +79,23 @@ def channel_shape(x, ch_axis):
     return shape
 
 
+def _dense(x):
+    """x as it lies in memory when that is one dense block (NCHW-contiguous or channels_last): per-tensor
+    kernels are layout-blind, so a channels_last activation needs no copy."""
+    if x.is_contiguous():
+        return x
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        return x
+    return x.contiguous()
+
+
 def fake_quant(x, scale, offset, lo, hi, form, g=0.0, y_kind=Y_DEQUANT, codes=None, want_y=True,
                out=None, ch_axis=None):
     """One-pass fake-quantisation.  Returns y, or (y, codes) when `codes` is "i8" / "p4"
     (y is None when want_y is False)."""
     N.require_gpu(x)
-    x = x.contiguous()
+    per_tensor = (not isinstance(scale, torch.Tensor)) or scale.numel() == 1
+    x = _dense(x) if per_tensor else x.contiguous()
     if x.dtype != torch.float32:
         raise TypeError(f"fake_quant computes in fp32; got {x.dtype}")
     scale, offset = _f32c(scale, x), _f32c(offset, x)
@@ -96,13 +107,13 @@ def fake_quant(x, scale, offset, lo, hi, form, g=0.0, y_kind=Y_DEQUANT, codes=No
             raise ValueError("offset must have one entry per scale entry")
     y = None
     if want_y:
-        y = out if out is not None else torch.empty_like(x)
-        if not (y.is_contiguous() and y.dtype == torch.float32 and y.shape == x.shape):
-            raise ValueError("out must be a contiguous fp32 tensor of x's shape")
+        y = out if out is not None else torch.empty_like(x)   # preserves x's memory format
+        if not (y.dtype == torch.float32 and y.shape == x.shape and y.stride() == x.stride()):
+            raise ValueError("out must be an fp32 tensor with x's shape and memory layout")
     cbuf, ckind = None, CODES_NONE
     n = x.numel()
     if codes == "i8":
-        cbuf = torch.empty(x.shape, dtype=torch.int8 if lo < 0 else torch.uint8, device=x.device)
+        cbuf = torch.empty_like(x, dtype=torch.int8 if lo < 0 else torch.uint8)   # same memory layout as x
         ckind = CODES_I8
     elif codes == "p4":
         cbuf = torch.empty((n + 1) // 2, dtype=torch.uint8, device=x.device)
@@ -211,6 +222,57 @@ def span_scale(vmax, neg_vmin, span):
     N.check(N.lib.dlmcq_span_scale_f32(N.ptr(vmax), N.ptr(neg_vmin), N.ptr(scale), vmax.numel(), float(span), 1,
                                        N.stream_ptr()))
     return scale
+
+
+def quantize_weight_krsc(w, scale, lo, hi):
+    """fp32 KCRS (or [K, C]) weights -> (int8 codes in KRSC order, int32 per-output-channel code sums)."""
+    N.require_gpu(w)
+    w = w.detach().contiguous()
+    K = w.shape[0]
+    C = w.shape[1]
+    R, S = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+    scale = _f32c(scale.detach(), w).reshape(-1)
+    if scale.numel() == 1:
+        scale = scale.expand(K).contiguous()
+    wq = torch.empty((K, R, S, C), dtype=torch.int8, device=w.device)
+    wsum = torch.empty(K, dtype=torch.int32, device=w.device)
+    N.check(N.lib.dlmcq_quantize_weight_krsc_i8(N.ptr(w), N.ptr(wq), N.ptr(wsum), N.ptr(scale), K, C, R, S, int(lo), int(hi),
+                                                N.stream_ptr()))
+    return wq, wsum
+
+
+def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1):
+    """Fused int8 conv / linear on the matrix cores.  `codes`: uint8/int8 activation codes, logically
+    (N, C, H, W) in channels_last memory, or (N, C) for a linear layer.  Returns fp32 (N, K, P, Q) in
+    channels_last memory (or (N, K))."""
+    N.require_gpu(codes, wq)
+    linear = codes.dim() == 2
+    if linear:
+        n, c = codes.shape
+        h = w_ = 1
+        codes = codes.contiguous()
+    else:
+        n, c, h, w_ = codes.shape
+        if not codes.is_contiguous(memory_format=torch.channels_last):
+            codes = codes.contiguous(memory_format=torch.channels_last)
+    K, R, S, _ = wq.shape
+    P = (h + 2 * padding - dilation * (R - 1) - 1) // stride + 1
+    Q = (w_ + 2 * padding - dilation * (S - 1) - 1) // stride + 1
+    if linear:
+        out = torch.empty((n, K), dtype=torch.float32, device=codes.device)
+    else:
+        out = torch.empty((n, K, P, Q), dtype=torch.float32, device=codes.device, memory_format=torch.channels_last)
+    w_scale = _f32c(w_scale.detach(), out).reshape(-1)
+    if w_scale.numel() == 1:
+        w_scale = w_scale.expand(K).contiguous()
+    in_scale = _f32c(in_scale.detach(), out).reshape(-1)
+    in_zp = None if in_zp is None else _f32c(in_zp, out).reshape(-1)
+    bias = None if bias is None else bias.detach().contiguous()
+    macs = n * P * Q * K * R * S * c
+    PROFILE.launch("conv_i8", codes.numel() + out.numel() * 4 + wq.numel(), lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(
+        N.ptr(codes), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),
+        n, h, w_, c, K, R, S, int(stride), int(padding), int(dilation), int(codes.dtype == torch.uint8), N.stream_ptr())))
+    return out
 
 
 def pack_int4(codes):

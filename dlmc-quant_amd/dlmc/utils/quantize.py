@@ -70,6 +70,8 @@ def quantize_model(model: nn.Module, config: Dict, logger=None, quantization_typ
             weight_cfg = _override_options(weight_cfg, overrides[name].get("weight"))
             input_cfg = _override_options(input_cfg, overrides[name].get("input"))
         layer_cfg = {"input": copy.deepcopy(input_cfg), "weight": copy.deepcopy(weight_cfg), "momentum": momentum}
+        if "int8_gemm" in kwargs or "int8_gemm" in config:   # opt-in fused int8 conv/linear (FSPTQ family)
+            layer_cfg["int8_gemm"] = bool(kwargs.get("int8_gemm", config.get("int8_gemm")))
         cls = mapping[type(layer)]
         wrapped = cls.__new__(cls)
         wrapped.__dict__.update(layer.__dict__)

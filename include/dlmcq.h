@@ -202,6 +202,33 @@ int dlmcq_repvgg_fuse_f32(const float* k3, const float* k1, float* out_kernel, f
                           float eps3, float eps1, float epsid, int64_t out_channels,
                           int64_t cin_per_group, dlmcq_stream_t stream);
 
+/* ---- fused int8-dequant x GEMM convolution / linear on the matrix cores ---- */
+
+/*
+ * Weights fp32 KCRS -> int8 codes in KRSC order (the reduction order of the implicit GEMM) with the
+ * SYMMETRIC form (q = clamp(R(w / scale[k]), lo, hi), FSPTQuant/base.py:149-152), plus wsum[k] = sum of the
+ * codes of output channel k (needed for the activation zero-point / uint8 shift correction).
+ */
+int dlmcq_quantize_weight_krsc_i8(const float* w, int8_t* wq, int32_t* wsum, const float* scale,
+                                  int64_t K, int64_t C, int64_t R, int64_t S, int32_t lo, int32_t hi,
+                                  dlmcq_stream_t stream);
+
+/*
+ * out[n,p,q,k] = in_scale * w_scale[k] * SUM_{r,s,c} (x[n,h,w,c] - zp) * wq[k,r,s,c]  + bias[k]
+ * i.e. F.conv2d(x', w', bias) of modules/conv.py:18-19 on the fake-quantised operands, with exact int32
+ * accumulation on v_mfma_i32_32x32x32_i8 (groups = 1).  Zero padding is padding of x' = 0, i.e. of x = zp.
+ *   x        integer codes, NHWC (uint8 when x_is_unsigned, else int8), 16-byte aligned, C % 64 == 0
+ *   w, wsum  from dlmcq_quantize_weight_krsc_i8
+ *   out      fp32 NHWC [N, P, Q, K];  bias [K] or NULL
+ *   in_scale, in_zero_point: device scalars (zero point must hold an integer value; NULL = 0); w_scale [K]
+ * A linear layer is the case H = W = R = S = 1.
+ */
+int dlmcq_conv2d_i8_nhwc_f32(const void* x, const int8_t* w, float* out, const float* bias,
+                             const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                             const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
+                             int64_t R, int64_t S, int32_t stride, int32_t pad, int32_t dilation,
+                             int32_t x_is_unsigned, dlmcq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

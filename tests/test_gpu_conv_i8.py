@@ -1,0 +1,111 @@
+"""The fused int8 conv / linear (K9) against an exact reference: float64 convolution of the dequantised
+operands on the CPU.  With unit scales and small codes the fp32 result must be the exact integer."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fakequant_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(2333 + seed)
+
+
+CASES = [  # N, C, H, W, K, R, stride, pad, dil
+    (2, 64, 9, 9, 64, 1, 1, 0, 1),
+    (3, 128, 8, 8, 256, 1, 2, 0, 1),      # 1x1 stride 2 (downsample), BN = 128 path
+    (2, 64, 10, 10, 64, 3, 1, 1, 1),
+    (2, 64, 11, 9, 128, 3, 2, 1, 1),
+    (1, 128, 7, 7, 192, 3, 1, 1, 1),      # K % 128 != 0 -> BN = 64 with a tail tile
+    (2, 64, 9, 9, 40, 3, 1, 2, 2),        # dilation, K < 64
+    (5, 64, 14, 14, 128, 3, 1, 1, 1),     # M = 980: not a multiple of 128
+]
+
+
+@pytest.mark.parametrize("unsigned", [True, False])
+def test_conv_i8_matches_float64_reference(unsigned):
+    from dlmc.quantization.scalar import kernels as K
+    for idx, (n, c, h, w, k, r, stride, pad, dil) in enumerate(CASES):
+        g = gen(idx)
+        lo, hi = (0, 255) if unsigned else (-127, 127)
+        codes = torch.randint(lo, hi + 1, (n, c, h, w), generator=g).to(torch.uint8 if unsigned else torch.int8)
+        zp = float(torch.randint(0, 9, (1,), generator=g)) if unsigned else 0.0
+        s_in = torch.tensor(0.0173)
+        wt = torch.randn(k, c, r, r, generator=g) * 0.05
+        s_w, _ = O.minmax_channel(wt, 8, True, ch_axis=0)
+        s_w = s_w + 1e-6
+        bias = torch.randn(k, generator=g)
+        qw_ref, wq_deq = O.fq_symmetric(wt, s_w, -127, 127)
+        # weight quantisation kernel: KRSC codes + sums
+        wq, wsum = K.quantize_weight_krsc(wt.to(DEV), s_w.to(DEV), -127, 127)
+        assert torch.equal(wq.cpu().to(torch.float32), qw_ref.permute(0, 2, 3, 1).contiguous()), f"case {idx} wq"
+        assert torch.equal(wsum.cpu().to(torch.float64), qw_ref.double().sum(dim=(1, 2, 3))), f"case {idx} wsum"
+        xq = (codes.double() - zp) * s_in.double()
+        ref = F.conv2d(xq, wq_deq.double(), bias.double(), stride=stride, padding=pad, dilation=dil)
+        got = K.conv2d_i8(codes.to(DEV).contiguous(memory_format=torch.channels_last), wq, wsum, bias.to(DEV),
+                          s_in.to(DEV), torch.tensor(zp).to(DEV), s_w.to(DEV), stride=stride, padding=pad, dilation=dil)
+        assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+        torch.testing.assert_close(got.cpu().double(), ref, rtol=2e-6, atol=2e-5, msg=lambda m: f"case {idx}: {m}")
+
+
+def test_conv_i8_exact_integers_and_linear():
+    from dlmc.quantization.scalar import kernels as K
+    g = gen(50)
+    # asymmetric small integers, unit scales: the fp32 output is the exact integer convolution
+    codes = torch.randint(0, 16, (2, 64, 6, 6), generator=g).to(torch.uint8)
+    wq_f = torch.randint(-7, 8, (96, 64, 3, 3), generator=g).float()
+    wq, wsum = K.quantize_weight_krsc(wq_f.to(DEV), torch.ones(96, 1, 1, 1, device=DEV), -127, 127)
+    ref = F.conv2d(codes.double() - 3.0, wq_f.double(), None, padding=1)
+    got = K.conv2d_i8(codes.to(DEV).contiguous(memory_format=torch.channels_last), wq, wsum, None,
+                      torch.ones(1, device=DEV), torch.tensor(3.0, device=DEV), torch.ones(96, device=DEV), padding=1)
+    assert torch.equal(got.cpu().double(), ref)
+    # linear: (N, C) x (K, C)^T with a K that is not a multiple of 64
+    x = torch.randint(0, 256, (37, 128), generator=g).to(torch.uint8)
+    wl = torch.randn(1000, 128, generator=g) * 0.03
+    s_w, _ = O.minmax_channel(wl, 8, True, ch_axis=0)
+    b = torch.randn(1000, generator=g)
+    wq, wsum = K.quantize_weight_krsc(wl.to(DEV), s_w.to(DEV), -127, 127)
+    ref = F.linear(x.double() * 0.02, O.fq_symmetric(wl, s_w, -127, 127)[1].double(), b.double())
+    got = K.conv2d_i8(x.to(DEV), wq, wsum, b.to(DEV), torch.tensor(0.02, device=DEV), None, s_w.to(DEV))
+    assert got.shape == (37, 1000)
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=2e-6, atol=2e-5)
+    # arguments the kernel cannot take are refused, not mis-computed
+    from dlmc._native import DlmcqError
+    with pytest.raises(DlmcqError):
+        K.conv2d_i8(torch.zeros(1, 48, 4, 4, dtype=torch.uint8, device=DEV).contiguous(memory_format=torch.channels_last),
+                    torch.zeros(8, 1, 1, 48, dtype=torch.int8, device=DEV), torch.zeros(8, dtype=torch.int32, device=DEV), None,
+                    torch.ones(1, device=DEV), None, torch.ones(8, device=DEV))
+
+
+def test_fsptq_model_int8_path_matches_fp32_path():
+    """The same quantised network through both conv paths: fp32 MIOpen conv of the fake-quantised operands
+    (reference-identical operands) vs the fused int8 MFMA path.  Ineligible layers (C = 3 stem) fall back."""
+    import copy
+    from torch import nn
+    from dlmc.quantization.scalar import kernels as K
+    from dlmc.utils.quantize import quantize_model
+    cfg = {"weight": {"enable": True, "type": "minmax_channel", "recon_type": "None", "args": {"n_bits": 8, "signed": True}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+           "exclude_layers": [], "override_options": []}
+    torch.manual_seed(2333)
+    base = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 128, 3, stride=2, padding=1), nn.ReLU(),
+                         nn.Conv2d(128, 64, 1), nn.ReLU(), nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(64, 10)).to(DEV).eval()
+    a, b = copy.deepcopy(base), copy.deepcopy(base)
+    quantize_model(a, copy.deepcopy(cfg), None, quantization_type="FSPTQ")
+    quantize_model(b, copy.deepcopy(cfg), None, quantization_type="FSPTQ", int8_gemm=True)
+    x = torch.randn(4, 3, 20, 20, device=DEV)
+    with torch.no_grad():
+        ra, rb = a(x), b(x)                      # calibration forward
+        K.PROFILE.enabled = True
+        K.PROFILE.reset()
+        ra, rb = a(x), b(x)
+        K.PROFILE.enabled = False
+    tags = [t for t, *_ in K.PROFILE.records]
+    assert tags.count("conv_i8") == 3           # conv 64->128, conv 128->64, linear 64->10; the C = 3 stem falls back
+    torch.testing.assert_close(rb, ra, rtol=1e-4, atol=1e-4)
+    # with autograd on, the int8 path steps aside (training uses the differentiable fp32 path)
+    out = b(x)
+    assert out.requires_grad
