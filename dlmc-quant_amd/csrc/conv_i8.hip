@@ -16,6 +16,8 @@
 // this kernel is HBM-bound (4 B written per MAC-row vs 1 B read), so the structure favours streaming: BM = 128
 // pixels x BN in {64, 128} channels per workgroup, 4 waves (one 32-row slab each), BK = 64, double-buffered LDS
 // with register staging (one barrier per K step), rows padded to 80 B so ds_read_b128 fragments are conflict-free.
+#include <cstdlib>
+
 #include "dlmcq_internal.h"
 
 namespace dlmcq {
@@ -81,18 +83,18 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__
   const int nsteps = g.R * g.S * cchunks;
   const int64_t wrow = (int64_t)g.R * g.S * g.C;  // bytes per output channel in KRSC
 
+  // Register staging, one step ahead; (r, s, c-chunk) advance incrementally - no integer division in the loop.
   i32x4 ra[2], rb[BLOADS];
-  auto fetch = [&](int step) {
-    const int cc = step % cchunks;
-    const int rs = step / cchunks;
-    const int s = rs % g.S, r = rs / g.S;
-    const int c0 = cc * CV_BK + seg * 16;
+  int f_cc = 0, f_s = 0, f_r = 0;   // tap / channel chunk of the NEXT fetch
+  auto fetch = [&]() {
+    const int c0 = f_cc * CV_BK + seg * 16;
+    const int rs = f_r * g.S + f_s;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int h = a_h0[i] + r * g.dil, ww = a_w0[i] + s * g.dil;
+      const int h = a_h0[i] + f_r * g.dil, ww = a_w0[i] + f_s * g.dil;
       if (a_ok[i] && h >= 0 && h < g.H && ww >= 0 && ww < g.W) {
         const int64_t off = (((int64_t)a_n[i] * g.H + h) * g.W + ww) * g.C + c0;
-        i32x4 v = *reinterpret_cast<const i32x4*>(x + off);
+        const i32x4 v = *reinterpret_cast<const i32x4*>(x + off);
         ra[i] = i32x4{(int)(v.x ^ xorw), (int)(v.y ^ xorw), (int)(v.z ^ xorw), (int)(v.w ^ xorw)};
       } else {
         ra[i] = i32x4{(int)padw, (int)padw, (int)padw, (int)padw};
@@ -105,6 +107,13 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__
         rb[i] = *reinterpret_cast<const i32x4*>(w + (int64_t)k * wrow + (int64_t)rs * g.C + c0);
       else
         rb[i] = i32x4{0, 0, 0, 0};
+    }
+    if (++f_cc == cchunks) {
+      f_cc = 0;
+      if (++f_s == g.S) {
+        f_s = 0;
+        ++f_r;
+      }
     }
   };
   auto stage = [&](int buf) {
@@ -122,13 +131,13 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0;
 
-  fetch(0);
+  fetch();
   stage(0);
   __syncthreads();
   const int arow = wave * 32 + (lane & 31), kq = (lane >> 5) * 16;
   for (int step = 0; step < nsteps; ++step) {
     const int buf = step & 1;
-    if (step + 1 < nsteps) fetch(step + 1);       // global loads in flight under the MFMAs below
+    if (step + 1 < nsteps) fetch();               // global loads in flight under the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < CV_BK / 32; ++ks) {
       const i32x4 af = *reinterpret_cast<const i32x4*>(ldsA + (buf * CV_BM + arow) * CV_LD + ks * 32 + kq);
@@ -154,7 +163,165 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int64_t row = m0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      if (row < g.M) out[row * g.K + col] = (float)(acc[j][i] + corr) * mult + bv;
+      if (row < g.M) __builtin_nontemporal_store((float)(acc[j][i] + corr) * mult + bv, out + row * g.K + col);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LDS-DMA variant: operands go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging), three LDS
+// buffers, two K steps in flight, ONE raw s_barrier per step with a counted s_waitcnt vmcnt.
+//   * a wave-instruction lands 64 lanes x 16 B = 16 rows x 64 B contiguously, so rows cannot be padded; bank
+//     conflicts are avoided by an XOR swizzle applied on the SOURCE side: LDS slot p of row r holds the logical
+//     16-byte segment p ^ ((r >> 2) & 3), and the fragment reads apply the same involution;
+//   * DMA cannot transform or synthesise bytes: the uint8 -> int8 shift (q ^ 0x80) is applied to the A fragment
+//     after the ds_read, and padded taps / rows beyond K read a 16-byte line of a constant table instead.
+struct PadTable {
+  int8_t b[256 * 16];
+  constexpr PadTable() : b() {
+    for (int v = 0; v < 256; ++v)
+      for (int j = 0; j < 16; ++j) b[v * 16 + j] = (int8_t)v;
+  }
+};
+__device__ const PadTable g_pad_table = PadTable();
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                         float* __restrict__ out, const float* __restrict__ bias,
+                                                         const int32_t* __restrict__ wsum,
+                                                         const float* __restrict__ s_in,
+                                                         const float* __restrict__ zp_in,
+                                                         const float* __restrict__ s_w, ConvGeom g, int shift) {
+  constexpr int NBUF = 3;
+  constexpr int TILE_A = CV_BM * CV_BK, TILE_B = BN * CV_BK, TILE = TILE_A + TILE_B;
+  constexpr int NT = BN / 32;
+  constexpr int BI = BN / 64;  // B wave-instructions per wave per step
+  __shared__ __attribute__((aligned(1024))) int8_t lds[NBUF * TILE];
+
+  const uint32_t nwg = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t qd = nwg >> 3, rm = nwg & 7u;
+  const uint32_t tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
+  const int bn = tile % g.nblk_n, bm = tile / g.nblk_n;
+  const int64_t m0 = (int64_t)bm * CV_BM;
+  const int n0 = bn * BN;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float zpf = zp_in ? zp_in[0] : 0.0f;
+  const int zpi = (int)__builtin_rintf(zpf);
+  const int8_t* padline = g_pad_table.b + ((zpi & 0xff) << 4);   // stored UNshifted: the xor happens on read
+  const uint32_t xorw = shift ? 0x80808080u : 0u;
+
+  // ---- DMA assignment: wave-instruction i of this wave covers tile rows (i*4 + wave)*16 .. +15 ----
+  const int lrow = lane >> 2, pslot = lane & 3;
+  int a_n[2], a_h0[2], a_w0[2], a_seg[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 4 + wave) * 16 + lrow;
+    a_seg[i] = pslot ^ ((row >> 2) & 3);
+    const int64_t m = m0 + row;
+    a_ok[i] = m < g.M;
+    const int64_t mm = a_ok[i] ? m : 0;
+    const int q = (int)(mm % g.Q);
+    const int64_t t = mm / g.Q;
+    const int p = (int)(t % g.P);
+    a_n[i] = (int)(t / g.P);
+    a_h0[i] = p * g.stride - g.pad;
+    a_w0[i] = q * g.stride - g.pad;
+  }
+  int b_seg[BI];
+  const int8_t* b_src[BI];
+  const int64_t wrow = (int64_t)g.R * g.S * g.C;
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int row = (i * 4 + wave) * 16 + lrow;
+    b_seg[i] = pslot ^ ((row >> 2) & 3);
+    const int k = n0 + row;
+    b_src[i] = k < g.K ? w + (int64_t)k * wrow : nullptr;
+  }
+  const int cchunks = g.C / CV_BK;
+  const int nsteps = g.R * g.S * cchunks;
+
+  int f_cc = 0, f_s = 0, f_r = 0, f_buf = 0;
+  auto issue = [&]() {
+    int8_t* base = lds + f_buf * TILE;
+    const int rs = f_r * g.S + f_s;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int h = a_h0[i] + f_r * g.dil, ww = a_w0[i] + f_s * g.dil;
+      const int8_t* src = padline;
+      if (a_ok[i] && h >= 0 && h < g.H && ww >= 0 && ww < g.W)
+        src = x + (((int64_t)a_n[i] * g.H + h) * g.W + ww) * g.C + f_cc * CV_BK + a_seg[i] * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int8_t* src = b_src[i] ? b_src[i] + (int64_t)rs * g.C + f_cc * CV_BK + b_seg[i] * 16 : g_pad_table.b;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + TILE_A + (i * 4 + wave) * 1024), 16, 0, 0);
+    }
+    if (++f_cc == cchunks) {
+      f_cc = 0;
+      if (++f_s == g.S) {
+        f_s = 0;
+        ++f_r;
+      }
+    }
+    if (++f_buf == NBUF) f_buf = 0;
+  };
+
+  i32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0;
+
+  const int arow = wave * 32 + (lane & 31), hsel = lane >> 5;
+  const int a_sw = (arow >> 2) & 3;
+  issue();
+  if (nsteps > 1) issue();
+  int c_buf = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    // step's own DMAs must have landed; the next step's group (2 + BI instructions) may stay in flight
+    if (step + 1 < nsteps) {
+      if (BI == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                 // everyone's step-k bytes are in LDS; everyone left multiply(k-1)
+    if (step + 2 < nsteps) issue();               // into the buffer multiply(k-1) just released
+    const int8_t* base = lds + c_buf * TILE;
+#pragma unroll
+    for (int ks = 0; ks < CV_BK / 32; ++ks) {
+      const int sg = ks * 2 + hsel;
+      i32x4 af = *reinterpret_cast<const i32x4*>(base + arow * 64 + ((sg ^ a_sw) << 4));
+      af = i32x4{(int)(af.x ^ xorw), (int)(af.y ^ xorw), (int)(af.z ^ xorw), (int)(af.w ^ xorw)};
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int brow = j * 32 + (lane & 31);
+        const i32x4 bf = *reinterpret_cast<const i32x4*>(base + TILE_A + brow * 64 + ((sg ^ ((brow >> 2) & 3)) << 4));
+        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[j], 0, 0, 0);
+      }
+    }
+    if (++c_buf == NBUF) c_buf = 0;
+  }
+
+  const float sin = s_in[0];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + j * 32 + (lane & 31);
+    if (col >= g.K) continue;
+    const float mult = sin * s_w[col];
+    const int corr = (shift - zpi) * wsum[col];
+    const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t row = m0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      if (row < g.M) __builtin_nontemporal_store((float)(acc[j][i] + corr) * mult + bv, out + row * g.K + col);
     }
   }
 }
@@ -200,6 +367,15 @@ extern "C" int dlmcq_quantize_weight_krsc_i8(const float* w, int8_t* wq, int32_t
   return launch_status();
 }
 
+static int conv_variant() {
+  // 1 = LDS-DMA pipeline (default), 0 = register-staged reference variant.  Read once; for A/B measurements only.
+  static const int v = [] {
+    const char* e = getenv("DLMCQ_CONV_VARIANT");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
 extern "C" int dlmcq_conv2d_i8_nhwc_f32(const void* x, const int8_t* w, float* out, const float* bias,
                                         const int32_t* wsum, const float* in_scale, const float* in_zero_point,
                                         const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
@@ -227,14 +403,22 @@ extern "C" int dlmcq_conv2d_i8_nhwc_f32(const void* x, const int8_t* w, float* o
     g.nblk_n = (int)((K + 63) / 64);
     const int64_t nwg = (int64_t)g.nblk_m * g.nblk_n;
     if (nwg >= (1ll << 31)) return DLMCQ_ERANGE;
-    hipLaunchKernelGGL((conv_i8_kernel<64>), dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale,
-                       in_zero_point, w_scale, g, shift);
+    if (conv_variant() == 1)
+      hipLaunchKernelGGL((conv_i8_dma_kernel<64>), dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale,
+                         in_zero_point, w_scale, g, shift);
+    else
+      hipLaunchKernelGGL((conv_i8_kernel<64>), dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale,
+                         in_zero_point, w_scale, g, shift);
   } else {
     g.nblk_n = (int)(K / 128);
     const int64_t nwg = (int64_t)g.nblk_m * g.nblk_n;
     if (nwg >= (1ll << 31)) return DLMCQ_ERANGE;
-    hipLaunchKernelGGL((conv_i8_kernel<128>), dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale,
-                       in_zero_point, w_scale, g, shift);
+    if (conv_variant() == 1)
+      hipLaunchKernelGGL((conv_i8_dma_kernel<128>), dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum,
+                         in_scale, in_zero_point, w_scale, g, shift);
+    else
+      hipLaunchKernelGGL((conv_i8_kernel<128>), dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale,
+                         in_zero_point, w_scale, g, shift);
   }
   return launch_status();
 }

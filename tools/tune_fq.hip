@@ -124,6 +124,60 @@ __global__ __launch_bounds__(BLOCK) void kobs(const float* x, float* part, long 
   }
 }
 
+
+// ---- codes-only prototypes (4 B read + 1 B written per element) ----
+__device__ __forceinline__ unsigned code4(f32x4 v, float s, float zp) {
+  float q0 = clampn(ster(v.x / s) + zp, 0.f, 255.f), q1 = clampn(ster(v.y / s) + zp, 0.f, 255.f);
+  float q2 = clampn(ster(v.z / s) + zp, 0.f, 255.f), q3 = clampn(ster(v.w / s) + zp, 0.f, 255.f);
+  return (unsigned)(int)q0 | ((unsigned)(int)q1 << 8) | ((unsigned)(int)q2 << 16) | ((unsigned)(int)q3 << 24);
+}
+// (a) lane i: float4 i of the chunk -> one dword store (256 B per wave-instruction)
+template <int BLOCK, int U>
+__global__ __launch_bounds__(BLOCK) void kcode_a(const float* x, unsigned* y, const float* sc, long n4) {
+  const float s = sc[0], zp = sc[1];
+  const f32x4* x4 = (const f32x4*)x;
+  const long nchunks = (n4 + BLOCK * U - 1) / (BLOCK * U);
+  for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const long i0 = c * (BLOCK * U) + threadIdx.x;
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (i0 + u * BLOCK < n4) v[u] = __builtin_nontemporal_load(x4 + i0 + u * BLOCK);
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (i0 + u * BLOCK < n4) __builtin_nontemporal_store(code4(v[u], s, zp), y + i0 + u * BLOCK);
+  }
+}
+// (b) lane i: four float4 at stride BLOCK (coalesced loads), codes exchanged so each lane stores 16 contiguous bytes
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void kcode_b(const float* x, unsigned* y, const float* sc, long n4) {
+  const float s = sc[0], zp = sc[1];
+  const f32x4* x4 = (const f32x4*)x;
+  const long nchunks = (n4 + BLOCK * 4 - 1) / (BLOCK * 4);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    // wave w handles 256 consecutive float4: sub-row u = float4s [u*64, u*64+64)
+    const long base = c * (BLOCK * 4) + wv * 256;
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (base + u * 64 + lane < n4) v[u] = __builtin_nontemporal_load(x4 + base + u * 64 + lane);
+    unsigned cd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cd[u] = code4(v[u], s, zp);
+    // dword d = u*64 + lane of this wave's 256 dwords; lane L wants dwords 4L..4L+3 = (u = L>>4, lanes 4(L&15)+j)
+    u32x4 o;
+    const int src = 4 * (lane & 15);
+    unsigned t0[4], t1[4], t2[4], t3[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { t0[u] = __shfl(cd[u], src + 0, 64); t1[u] = __shfl(cd[u], src + 1, 64); t2[u] = __shfl(cd[u], src + 2, 64); t3[u] = __shfl(cd[u], src + 3, 64); }
+    const int uu = lane >> 4;
+    o.x = uu == 0 ? t0[0] : uu == 1 ? t0[1] : uu == 2 ? t0[2] : t0[3];
+    o.y = uu == 0 ? t1[0] : uu == 1 ? t1[1] : uu == 2 ? t1[2] : t1[3];
+    o.z = uu == 0 ? t2[0] : uu == 1 ? t2[1] : uu == 2 ? t2[2] : t2[3];
+    o.w = uu == 0 ? t3[0] : uu == 1 ? t3[1] : uu == 2 ? t3[2] : t3[3];
+    if (base + 4 * lane < n4) __builtin_nontemporal_store(o, (u32x4*)(y + base) + lane);
+  }
+}
+
 struct Var { const char* name; void (*fn)(const float*, float*, const float*, long); int block, u, copy; };
 
 #define V(B, U, NL, NS, M) {#B "x" #U " ntl=" #NL " nts=" #NS, (void (*)(const float*, float*, const float*, long))k<B, U, NL, NS, M>, B, U, M}
@@ -225,7 +279,34 @@ int main(int argc, char** argv) {
       fflush(stdout);
     }
   }
+
+  // ---- codes-only sweep ----
+  {
+    struct CV { const char* name; void (*fn)(const float*, unsigned*, const float*, long); int block, u; };
+#define CA(B, U) {"a " #B "x" #U, (void (*)(const float*, unsigned*, const float*, long))kcode_a<B, U>, B, U}
+#define CB(B) {"b " #B "x4", (void (*)(const float*, unsigned*, const float*, long))kcode_b<B>, B, 4}
+    CV cvs[] = {CA(64, 1), CA(64, 2), CA(64, 4), CA(64, 8), CA(256, 1), CA(256, 2), CA(256, 4), CA(256, 8), CB(64), CB(256)};
+    long caps[] = {0, 2048, 8192};
+    for (auto& v : cvs) for (long cap : caps) {
+      long nchunks = (n4 + (long)v.block * v.u - 1) / ((long)v.block * v.u);
+      long grid = cap == 0 ? nchunks : std::min(cap, nchunks);
+      if (cap != 0 && grid == nchunks) continue;
+      std::vector<float> ts;
+      for (int it = 0; it < iters + 3; ++it) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL(v.fn, dim3((unsigned)grid), dim3(v.block), 0, 0, xs[it % nbuf], (unsigned*)ys[it % nbuf], sc, n4);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (it >= 3) ts.push_back(ms);
+      }
+      std::sort(ts.begin(), ts.end());
+      double med = ts[ts.size() / 2];
+      printf("CODE  %-10s grid %-8ld med %8.2f us %7.1f GB/s\n", v.name, grid, med * 1e3, 5.0 * n / med / 1e6);
+      fflush(stdout);
+    }
+  }
   return 0;
+
 
 
 }
