@@ -172,13 +172,21 @@ def int8_layer_ok(mod):
     return w.shape[1] % 64 == 0 and sq(mod.stride) and sq(mod.padding) and sq(mod.dilation)
 
 
-def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, wt_lo, wt_hi):
+def ste_scale_value(scale, g):
+    """Forward value of the reference's grad_scale on a (tiny) scale tensor: (s - s*g) + s*g."""
+    sg = scale.detach() * g
+    return (scale.detach() - sg) + sg
+
+
+def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, wt_lo, wt_hi, g_in=0.0):
     """Quantise the activation to integer codes (one pass, 4 B read + 1 B written per element), quantise the
     weight to KRSC int8, and contract on v_mfma_i32_32x32x32_i8 with the dequantisation fused into the epilogue.
     Same mathematical result as F.conv2d(fake_quant(x), fake_quant(w), bias); activations travel channels_last."""
     if input.dim() == 4 and not input.is_contiguous(memory_format=torch.channels_last):
         input = input.contiguous(memory_format=torch.channels_last)   # one transposing copy, at the model's first int8 layer
-    _, codes = K.fake_quant(input, in_scale.detach(), in_zp, in_lo, in_hi, act_form, codes="i8", want_y=False)
+    _, codes = K.fake_quant(input, in_scale.detach(), in_zp, in_lo, in_hi, act_form, g=g_in, codes="i8", want_y=False)
+    if g_in:
+        in_scale = ste_scale_value(in_scale, g_in)   # QBASE dequantises with s^, not s
     wq, wsum = K.quantize_weight_krsc(mod.weight, wt_scale, wt_lo, wt_hi)
     if mod.weight.dim() == 2:
         flat = codes.reshape(-1, codes.shape[-1])

@@ -22,7 +22,8 @@ from torch.nn import Module
 
 from .... import _native as N
 from .. import ops
-from .._wrapper import InitState, fake_quant, set_scale
+from .._wrapper import (InitState, fake_quant, int8_forward, int8_gemm_default, int8_layer_ok, set_scale,
+                        ste_scale_value)
 from ..utils import get_qrange
 
 
@@ -50,6 +51,21 @@ class QBase(Module):
         self.register_buffer("wt_offset", None)
         self.register_buffer("wt_init_state", torch.zeros(1, device=dev))
         self._init = InitState()
+        # fused int8 conv/linear on the matrix cores: opt-in; needs symmetric (zero-offset) per-tensor quantisers
+        self.int8_gemm = bool(qconfig.get("int8_gemm", int8_gemm_default()))
+        self._int8_offsets_zero = None
+
+    def _int8_applicable(self):
+        cfg = self.qconfig
+        if not (self.int8_gemm and cfg["input"]["enable"] and cfg["weight"]["enable"]) or torch.is_grad_enabled():
+            return False
+        if self.in_scale.numel() != 1 or self.wt_scale.numel() != 1 or not int8_layer_ok(self):
+            return False
+        if not (-128 <= self.in_min_val and self.in_max_val <= 127 and -128 <= self.wt_min_val and self.wt_max_val <= 127):
+            return False
+        if self._int8_offsets_zero is None:   # one host read, right after calibration
+            self._int8_offsets_zero = bool(float(self.in_offset.abs().max()) == 0 and float(self.wt_offset.abs().max()) == 0)
+        return self._int8_offsets_zero
 
     def reset_qparams(self):
         """Forget the calibrated scales: the next forward observes again."""
@@ -74,6 +90,7 @@ class QBase(Module):
                 getattr(self, name).data = torch.ones_like(state_dict[key], dtype=torch.float32, device=self.weight.device)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
         self._init.invalidate()
+        self._int8_offsets_zero = None
 
     def _forward_func(self, input, weight):
         raise NotImplementedError
@@ -93,6 +110,7 @@ class QBase(Module):
             scale, offset = ops.get_qparams_tensor(x, qtype=cfg["type"], **kw)
         set_scale(self.in_scale, scale)
         self.in_offset = offset.detach().to(torch.float32)
+        self._int8_offsets_zero = None
         self._init.mark(self, "in_init_state")
 
     def _calibrate_weight(self, input):
@@ -112,6 +130,17 @@ class QBase(Module):
     # ----------------------------------------------------------------------------- forward
     def forward(self, input):
         N.require_gpu(input, self.weight)
+        if self.int8_gemm and not torch.is_grad_enabled():
+            if self.qconfig["input"]["enable"] and not self._init.ready(self, "in_init_state"):
+                self._calibrate_input(input)
+            if self.qconfig["weight"]["enable"] and not self._init.ready(self, "wt_init_state") and \
+                    not fnmatch(str(self.qconfig["weight"]["type"]), "*output*"):
+                self._calibrate_weight(input)
+            if self._init.ready(self, "wt_init_state") and self._int8_applicable():
+                g_i = 1 / math.sqrt(input.numel() * self.in_max_val)
+                g_w = 1 / math.sqrt(self.weight.numel() * self.wt_max_val)
+                return int8_forward(self, input, self.in_scale, None, self.in_min_val, self.in_max_val, N.FORM_QBASE,
+                                    ste_scale_value(self.wt_scale, g_w), self.wt_min_val, self.wt_max_val, g_in=g_i)
         if self.qconfig["input"]["enable"]:
             if not self._init.ready(self, "in_init_state"):
                 self._calibrate_input(input)

@@ -109,3 +109,41 @@ def test_fsptq_model_int8_path_matches_fp32_path():
     # with autograd on, the int8 path steps aside (training uses the differentiable fp32 path)
     out = b(x)
     assert out.requires_grad
+
+
+def test_qbase_model_int8_path_matches_fp32_path():
+    """QBase family (signed symmetric W8A8, per tensor): int8 MFMA path vs the fp32 path."""
+    import copy
+    from torch import nn
+    from dlmc.quantization.scalar import kernels as K
+    from dlmc.utils.quantize import quantize_model
+    cfg = {"weight": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": True}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": True}},
+           "exclude_layers": [], "override_options": []}
+    torch.manual_seed(2333)
+    base = nn.Sequential(nn.Conv2d(64, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 128, 1, stride=2), nn.ReLU(),
+                         nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(128, 10)).to(DEV).eval()
+    a, b = copy.deepcopy(base), copy.deepcopy(base)
+    quantize_model(a, copy.deepcopy(cfg), None)
+    quantize_model(b, copy.deepcopy(cfg), None, int8_gemm=True)
+    x = torch.randn(4, 64, 12, 12, device=DEV)
+    with torch.no_grad():
+        a(x), b(x)
+        K.PROFILE.enabled = True
+        K.PROFILE.reset()
+        ra, rb = a(x), b(x)
+        K.PROFILE.enabled = False
+    assert [t for t, *_ in K.PROFILE.records].count("conv_i8") == 3
+    torch.testing.assert_close(rb, ra, rtol=1e-4, atol=1e-4)
+    # an asymmetric (unsigned, offset = min != 0) QBase layer is not int8-able and silently keeps the fp32 path
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["input"]["args"]["signed"] = False
+    c = copy.deepcopy(base)
+    quantize_model(c, cfg2, None, int8_gemm=True)
+    with torch.no_grad():
+        c(x)
+        K.PROFILE.enabled = True
+        K.PROFILE.reset()
+        c(x)
+        K.PROFILE.enabled = False
+    assert [t for t, *_ in K.PROFILE.records].count("conv_i8") <= 2   # only the post-ReLU (min = 0) layers qualify
