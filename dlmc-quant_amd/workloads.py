@@ -146,6 +146,43 @@ class RepVGGDeploy(nn.Module):
         return self.linear(torch.flatten(self.gap(x), 1))
 
 
+class MobileOneDeployBlock(nn.Module):
+    """A re-parameterised MobileOne unit: depthwise 3x3 (+bias, ReLU) then pointwise 1x1 (+bias, ReLU)."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.dw = nn.Conv2d(cin, cin, 3, stride=stride, padding=1, groups=cin, bias=True)
+        self.pw = nn.Conv2d(cin, cout, 1, bias=True)
+        self.act = nn.ReLU()
+
+    def forward(self, x):
+        return self.act(self.pw(self.act(self.dw(x))))
+
+
+class MobileOneDeploy(nn.Module):
+    """MobileOne in inference form (public architecture, Vasu et al. 2022; NOT in the reference - BASELINE
+    config 5 only borrows its layer shapes).  S1: width multipliers (1.5, 1.5, 2.0, 2.5), blocks (2, 8, 10, 1)."""
+
+    def __init__(self, widths=(1.5, 1.5, 2.0, 2.5), blocks=(2, 8, 10, 1), num_classes=1000):
+        super().__init__()
+        cin = min(64, int(64 * widths[0]))
+        self.stage0 = nn.Sequential(nn.Conv2d(3, cin, 3, stride=2, padding=1, bias=True), nn.ReLU())
+        stages = []
+        for base, mult, n in zip((64, 128, 256, 512), widths, blocks):
+            cout = int(base * mult)
+            stages.append(nn.Sequential(*[MobileOneDeployBlock(cin if j == 0 else cout, cout, 2 if j == 0 else 1)
+                                          for j in range(n)]))
+            cin = cout
+        self.stage1, self.stage2, self.stage3, self.stage4 = stages
+        self.gap = nn.AdaptiveAvgPool2d(1)
+        self.linear = nn.Linear(cin, num_classes)
+        _init(self)
+
+    def forward(self, x):
+        x = self.stage4(self.stage3(self.stage2(self.stage1(self.stage0(x)))))
+        return self.linear(torch.flatten(self.gap(x), 1))
+
+
 def _init(model):
     for m in model.modules():
         if isinstance(m, nn.Conv2d):
@@ -170,7 +207,11 @@ def repvgg_a1_deploy(num_classes=1000):
     return RepVGGDeploy((2, 4, 14, 1), (64, 64, 128, 256, 1280), num_classes)
 
 
-MODELS = {"resnet18": resnet18, "resnet50": resnet50, "repvgg_a1": repvgg_a1_deploy}
+def mobileone_s1_deploy(num_classes=1000):
+    return MobileOneDeploy(num_classes=num_classes)
+
+
+MODELS = {"resnet18": resnet18, "resnet50": resnet50, "repvgg_a1": repvgg_a1_deploy, "mobileone_s1": mobileone_s1_deploy}
 
 
 def layer_table(model, x):

@@ -376,3 +376,55 @@ def test_merge_bn_and_repvgg_reparam(golden):
             assert_bits_equal(dep.rbr_reparam.weight, golden.get(c, "out_kernel"), c["name"] + ".kernel")
             assert_bits_equal(dep.rbr_reparam.bias, golden.get(c, "out_bias"), c["name"] + ".bias")
             close(dep(x), ref.cpu(), c["name"] + " output", rtol=1e-4, atol=1e-4)
+
+
+def test_config5_mobileone_w4a8_asymmetric_per_channel():
+    """BASELINE config 5 at small batch: MobileOne-S1 (deploy form, build-owned shapes), W4 asymmetric per-channel
+    (`minmax_channel`, unsigned 4 bit: codes 0..15, float offset = channel min, ops.py:129-136), A u8 per tensor;
+    nibble pack/unpack of the weight codes; RootQ weight forward at 4 bit."""
+    import workloads as W
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    from dlmc.quantization.scalar import modules
+    from dlmc.utils.quantize import quantize_model
+    from oracle import fakequant_oracle as O
+    torch.manual_seed(2333)
+    net = W.mobileone_s1_deploy().to(DEV).eval()
+    cfg = {"weight": {"enable": True, "type": "minmax_channel", "args": {"n_bits": 4, "signed": False}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+           "exclude_layers": [], "override_options": []}
+    quantize_model(net, cfg, None)
+    layers = [(n, m) for n, m in net.named_modules() if isinstance(m, modules.QBase)]
+    assert len(layers) == 44
+    seen = {}
+    hooks = [m.register_forward_pre_hook(lambda mod, inp, n=n: seen.__setitem__(n, inp[0].detach().cpu())) for n, m in layers]
+    caps = {n: Capture(m) for n, m in layers}
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        out = net(x.to(DEV))
+    assert out.shape == (2, 1000) and torch.isfinite(out).all()
+    for n, m in layers[:6] + layers[-3:]:
+        xin, w = seen[n], m.weight.detach().cpu()
+        s_in, o_in = O.minmax_tensor(xin, 8, False)
+        s_wt, o_wt = O.minmax_channel(w, 4, False, ch_axis=0)
+        assert m.wt_scale.shape == s_wt.shape
+        want_x = O.fq_qbase(xin, s_in, o_in, 0, 255, 1 / math.sqrt(xin.numel() * 255))[1]
+        qw, want_w = O.fq_qbase(w, s_wt, o_wt, 0, 15, 1 / math.sqrt(w.numel() * 15))
+        assert_bits_equal(caps[n].input, want_x, n + ".fq_input")
+        assert_bits_equal(caps[n].weight, want_w, n + ".fq_weight")
+        # W4 codes: emitted packed (two per byte), unpacked, and dequantised back to the same fake-quant weights
+        g_w = 1 / math.sqrt(w.numel() * 15)
+        _, packed = K.fake_quant(m.weight.detach(), m.wt_scale, m.wt_offset, 0, 15, N.FORM_QBASE, g=g_w, codes="p4", want_y=False)
+        assert packed.numel() == (w.numel() + 1) // 2
+        codes = K.unpack_int4(packed, w.numel(), False).cpu().to(torch.float32).reshape(w.shape)
+        assert torch.equal(codes, qw), n + ".w4 codes"
+        assert torch.equal(K.pack_int4(codes.to(torch.int8).to(DEV)).cpu(), packed.cpu()), n + ".pack"
+        back = K.dequant_codes(packed, w.shape, m.wt_scale, m.wt_offset, N.FORM_QBASE, "p4", False, g=g_w)
+        assert_bits_equal(back, want_w, n + ".dequant(p4)")
+    for h in hooks:
+        h.remove()
+    # RootQ weight forward at 4 bit on a pointwise weight of the net
+    w = layers[4][1].weight.detach()
+    up, lw = (2 * w.abs().mean() * math.sqrt(15)).cpu(), (-2 * w.abs().mean() * math.sqrt(15)).cpu()
+    want = O.fq_rootq_weight(w.cpu(), up, lw, torch.tensor(0.25), 0, 15)[2]
+    assert_bits_equal(K.rootq_weight(w, up.to(DEV), lw.to(DEV), 0, 15), want, "rootq w4")

@@ -139,3 +139,9 @@ def test_unknown_qtype_raises_keyerror_like_the_reference():
     from dlmc.quantization.scalar import ops
     with pytest.raises(KeyError):
         ops.get_qparams_tensor(torch.zeros(4), "no_such_estimator", n_bits=8, signed=True)
+
+
+def test_mobileone_s1_matches_the_published_size():
+    rows = W.layer_table(W.mobileone_s1_deploy(), torch.zeros(1, 3, 224, 224))
+    layers, act, wt, macs = W.table_totals(rows)
+    assert layers == 44 and 4.7e6 < wt < 4.8e6 and 8.2e8 < macs < 8.3e8   # 4.8 M parameters, 825 MFLOPs (paper)
