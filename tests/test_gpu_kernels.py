@@ -398,3 +398,31 @@ def test_full_size_properties(K):
     wq = K.fake_quant(W, s_w + 1e-6, None, -127, 127, n.FORM_SYMMETRIC)
     assert_bits_equal(wq, O.fq_symmetric(W.cpu(), s_w.cpu() + 1e-6, -127, 127)[1], "W per channel")
     assert ulp_distance(wq, O.fq_symmetric(W.cpu(), s_w.cpu() + 1e-6, -127, 127)[1]) == 0
+
+
+def test_beyond_2_to_31_elements(K):
+    """Maximum sizes: a per-tensor pass over more than 2^31 elements (8.6 GB in, 8.6 GB out) - the index math is
+    64-bit; checked on the first and last megabyte against the oracle, and the observer must see an extreme
+    planted in the very last element."""
+    n = (1 << 31) + 4096 + 3
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3 * n * 4:
+        pytest.skip("not enough free HBM for the 2^31-element case")
+    nn_ = N()
+    x = torch.empty(n, device=DEV)
+    x.normal_(generator=torch.Generator(device=DEV).manual_seed(2333))
+    x[-1] = 77.0
+    x[n // 2] = -55.0
+    s, o = K.observe_qparams(x, 8, False)
+    assert float(o) == -55.0 and float(s) == float((torch.tensor(77.0) - torch.tensor(-55.0)) / 255)
+    sa, _ = K.observe_qparams(x, 8, True)
+    assert float(sa) == float(torch.tensor(77.0) / 127)
+    y = K.fake_quant(x, s, o, 0, 255, nn_.FORM_EMULATE)
+    _, codes = K.fake_quant(x, s, o, 0, 255, nn_.FORM_EMULATE, codes="i8", want_y=False)
+    m = 1 << 18
+    for sl in (slice(0, m), slice(n - m, n), slice((1 << 31) - m // 2, (1 << 31) + m // 2)):
+        q_ref, y_ref = O.fq_emulate(x[sl].cpu(), s.cpu(), o.cpu(), 0, 255)
+        assert_bits_equal(y[sl], y_ref, f"slice {sl}")
+        assert torch.equal(codes[sl].cpu().to(torch.float32), q_ref)
+    del y, codes, x
+    torch.cuda.empty_cache()

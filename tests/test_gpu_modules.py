@@ -428,3 +428,43 @@ def test_config5_mobileone_w4a8_asymmetric_per_channel():
     up, lw = (2 * w.abs().mean() * math.sqrt(15)).cpu(), (-2 * w.abs().mean() * math.sqrt(15)).cpu()
     want = O.fq_rootq_weight(w.cpu(), up, lw, torch.tensor(0.25), 0, 15)[2]
     assert_bits_equal(K.rootq_weight(w, up.to(DEV), lw.to(DEV), 0, 15), want, "rootq w4")
+
+
+def test_integer_checkpoint_roundtrip():
+    """int8 / packed-int4 export -> load into a fresh quantised model: identical outputs, 4-8x smaller weights."""
+    from dlmc.utils.export import export_quantized_state, load_quantized_state
+    from dlmc.utils.quantize import quantize_model
+
+    def build(family, wbits, wsigned, wtype):
+        torch.manual_seed(2333)
+        net = nn.Sequential(nn.Conv2d(3, 16, 3, padding=1), nn.ReLU(), nn.Conv2d(16, 32, 3, stride=2, padding=1), nn.ReLU(),
+                            nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(32, 10)).to(DEV).eval()
+        cfg = {"weight": {"enable": True, "type": wtype, "recon_type": "None", "args": {"n_bits": wbits, "signed": wsigned}},
+               "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+               "exclude_layers": [], "override_options": []}
+        quantize_model(net, cfg, None, quantization_type=family)
+        return net
+
+    x = torch.randn(4, 3, 16, 16, device=DEV)
+    for family, wbits, wsigned, wtype in (("FSPTQ", 8, True, "minmax_channel"), ("FSPTQ", 4, True, "minmax_channel"),
+                                          (None, 8, True, "minmax_tensor"), (None, 4, False, "minmax_channel")):
+        a = build(family, wbits, wsigned, wtype)
+        with torch.no_grad():
+            ref = a(x)
+        blob = export_quantized_state(a)
+        buf = io.BytesIO()
+        torch.save(blob, buf)
+        buf.seek(0)
+        blob = torch.load(buf, weights_only=False)
+        for name, rec in blob["layers"].items():
+            n = math.prod(rec["shape"])
+            assert rec["codes"].numel() == ((n + 1) // 2 if wbits <= 4 else n) and rec["codes"].element_size() == 1
+        b = build(family, wbits, wsigned, wtype)
+        with torch.no_grad():
+            b[0].weight.mul_(3.0)                      # make sure the weights really come from the file
+        load_quantized_state(b, blob)
+        with torch.no_grad():
+            out = b(x)                                 # no re-calibration: init flags came with the file
+        assert torch.equal(out, ref), (family, wbits, wsigned)
+    with pytest.raises(RuntimeError, match="calibrated"):
+        export_quantized_state(build("FSPTQ", 8, True, "minmax_channel"))
