@@ -13,7 +13,7 @@ from ..._native import (CODES_I8, CODES_NONE, CODES_P4, FORM_EMULATE, FORM_QBASE
                         Y_CODES, Y_DEQUANT)
 
 __all__ = ["fake_quant", "dequant_codes", "dequant", "minmax", "observe_qparams", "qparams_from_minmax",
-           "span_scale", "quantize_weight_krsc", "conv2d_i8", "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
+           "span_scale", "l2norm_step", "quantize_weight_krsc", "conv2d_i8", "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
            "PROFILE"]
 
 
@@ -222,6 +222,22 @@ def span_scale(vmax, neg_vmin, span):
     N.check(N.lib.dlmcq_span_scale_f32(N.ptr(vmax), N.ptr(neg_vmin), N.ptr(scale), vmax.numel(), float(span), 1,
                                        N.stream_ptr()))
     return scale
+
+
+def l2norm_step(x, scale, offset, lo, hi, ch_axis=None):
+    """One fused iteration of the l2norm refinement: returns the new scale, shaped like `scale`."""
+    N.require_gpu(x)
+    x = x.detach().contiguous()
+    sc, off = _f32c(scale.detach(), x), _f32c(offset, x)
+    outer, ch, inner = geometry(x, sc, ch_axis)
+    if off is not None and off.numel() != sc.numel():
+        off = off.reshape(1).expand(sc.numel()).contiguous()
+    new = torch.empty(ch, dtype=torch.float32, device=x.device)
+    nb = N.lib.dlmcq_l2norm_scratch_bytes(outer, ch, inner)
+    scr = _scratch(nb, x.device)
+    N.check(N.lib.dlmcq_l2norm_step_f32(N.ptr(x), N.ptr(sc), N.ptr(off), N.ptr(new), outer, ch, inner, int(lo), int(hi),
+                                        N.ptr(scr), scr.numel() * 4, N.stream_ptr()))
+    return new.reshape(scale.shape)
 
 
 def quantize_weight_krsc(w, scale, lo, hi):

@@ -2,10 +2,10 @@
 (dlmc/quantization/scalar/ops.py:11-18: `globals()["quantize_" + qtype]`, unknown names raise KeyError).
 
 minmax_* are the hot observers: one read of the tensor through the HIP reduction, the scale/offset
-arithmetic on device, no host sync and no transposed copy.  The iterative estimators (l2norm_*,
-l2loss_*) are calibration-time only; they keep the reference's control flow and run every tensor-sized
-step on the GPU (the HIP quantize kernel + device reductions) - fusing each iteration into one launch is
-a "next" row.
+arithmetic on device, no host sync and no transposed copy.  The iterative estimators are
+calibration-time only and keep the reference's control flow: l2norm_tensor / l2norm_channel run one fused
+HIP launch per iteration (quantize + both reductions, `dlmcq_l2norm_step_f32`); the output-aware and
+shrink-search variants run every tensor-sized step on the GPU with the HIP quantize kernel + device reductions.
 """
 import torch
 
@@ -80,8 +80,7 @@ def quantize_l2norm_tensor(tensor, n_bits, signed):
     lo, hi = get_qrange(signed, n_bits)
     diff = float("inf")
     while diff > 1e-5:
-        q = quantize(tensor, scale, offset, lo, hi)
-        new_scale = (tensor * q).sum() / (q * q + 1e-7).sum()
+        new_scale = K.l2norm_step(tensor, scale, offset, lo, hi)     # quantize + both reductions, one read
         diff = float((new_scale - scale).abs() / scale)
         scale = new_scale
     return scale, offset
@@ -95,8 +94,7 @@ def quantize_l2norm_channel(tensor, n_bits, signed, ch_axis=0):
     lo, hi = get_qrange(signed, n_bits)
     diff = float("inf")
     while diff > 1e-5:
-        q = quantize(rows, scale, offset, lo, hi)
-        new_scale = ((rows * q).sum(axis=1) / (q * q + 1e-7).sum(axis=1)).reshape(scale.shape)
+        new_scale = K.l2norm_step(rows, scale, offset, lo, hi)       # per-row sums, one read
         diff = float(((new_scale - scale) ** 2).sum().sqrt() / (scale ** 2).sum().sqrt())
         scale = new_scale
     return scale.reshape(new_shape), offset.reshape(new_shape)

@@ -202,6 +202,18 @@ int dlmcq_repvgg_fuse_f32(const float* k3, const float* k1, float* out_kernel, f
                           float eps3, float eps1, float epsid, int64_t out_channels,
                           int64_t cin_per_group, dlmcq_stream_t stream);
 
+/* ---- calibration-time estimators (ops.py:71-83, :198-215) ---- */
+
+/*
+ * One iteration of the l2norm scale refinement, fused: q = clamp(r((x-o)/(s+1e-7)), lo, hi),
+ * new_scale[c] = SUM x*q / SUM (q*q + 1e-7), one read of x.  Order-dependent fp32/fp64 sums: equal to the
+ * reference to summation tolerance.  scratch: dlmcq_l2norm_scratch_bytes().
+ */
+size_t dlmcq_l2norm_scratch_bytes(int64_t outer, int64_t channels, int64_t inner);
+int dlmcq_l2norm_step_f32(const float* x, const float* scale, const float* offset, float* new_scale,
+                          int64_t outer, int64_t channels, int64_t inner, int32_t lo, int32_t hi,
+                          void* scratch, size_t scratch_bytes, dlmcq_stream_t stream);
+
 /* ---- fused int8-dequant x GEMM convolution / linear on the matrix cores ---- */
 
 /*

@@ -426,3 +426,27 @@ def test_beyond_2_to_31_elements(K):
         assert torch.equal(codes[sl].cpu().to(torch.float32), q_ref)
     del y, codes, x
     torch.cuda.empty_cache()
+
+
+def test_l2norm_step_vs_oracle(K):
+    """One fused refinement iteration == quantize + two reductions of the reference (ops.py:78-79, :206-207)."""
+    for k, (shape, ch_axis) in enumerate([((70001,), None), ((8, 16, 28, 28), None), ((64, 32, 3, 3), 0), ((6, 24, 14, 14), 1),
+                                          ((33, 130), 1)]):
+        for signed, bits in ((True, 8), (False, 4)):
+            lo, hi = O.qrange(signed, bits)
+            g = gen(700 + k)
+            x = torch.randn(shape, generator=g)
+            if not signed:
+                x = torch.relu(x) + 0.01
+            if ch_axis is None:
+                s, o = O.minmax_tensor(x, bits, signed)
+                q = O.quantize_codes(x, s, o, lo, hi)
+                want = (x * q).sum().double() / (q * q + 1e-7).sum().double()
+            else:
+                s, o = O.minmax_channel(x, bits, signed, ch_axis=ch_axis)
+                q = O.quantize_codes(x, s, o, lo, hi)
+                red = tuple(i for i in range(x.dim()) if i != ch_axis)
+                want = ((x * q).double().sum(dim=red) / (q * q + 1e-7).double().sum(dim=red)).reshape(s.shape)
+            got = K.l2norm_step(x.to(DEV), s.to(DEV), o.to(DEV), lo, hi)
+            assert got.shape == s.shape
+            torch.testing.assert_close(got.cpu().double(), want, rtol=2e-5, atol=0)
