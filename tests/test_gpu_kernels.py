@@ -450,3 +450,44 @@ def test_l2norm_step_vs_oracle(K):
             got = K.l2norm_step(x.to(DEV), s.to(DEV), o.to(DEV), lo, hi)
             assert got.shape == s.shape
             torch.testing.assert_close(got.cpu().double(), want, rtol=2e-5, atol=0)
+
+
+def test_entry_points_are_graph_capturable(K):
+    """include/dlmcq.h promises no allocation / synchronisation inside the library: the observer, the fake-quant
+    and the int8 conv can be captured into one HIP graph (through torch.cuda.CUDAGraph) and replayed."""
+    n = N()
+    g = gen(900)
+    x = torch.rand(8, 64, 14, 14, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 64, 3, 3, generator=g) * 0.05).to(DEV)
+    s_w, _ = K.observe_qparams(w, 8, True, ch_axis=0, scale_eps=1e-6)
+    static_x = x.clone(memory_format=torch.preserve_format)
+    outs = {}
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):            # warm-up on the side stream, as graph capture requires
+        for _ in range(2):
+            s, o = K.observe_qparams(static_x, 8, False)
+            _, codes = K.fake_quant(static_x, s, o, 0, 255, n.FORM_ZEROPOINT, codes="i8", want_y=False)
+            wq, wsum = K.quantize_weight_krsc(w, s_w, -127, 127)
+            K.conv2d_i8(codes, wq, wsum, None, s, o, s_w, padding=1)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        s, o = K.observe_qparams(static_x, 8, False)
+        y = K.fake_quant(static_x, s, o, 0, 255, n.FORM_ZEROPOINT)
+        _, codes = K.fake_quant(static_x, s, o, 0, 255, n.FORM_ZEROPOINT, codes="i8", want_y=False)
+        wq, wsum = K.quantize_weight_krsc(w, s_w, -127, 127)
+        outs["conv"] = K.conv2d_i8(codes, wq, wsum, None, s, o, s_w, padding=1)
+        outs["y"], outs["s"] = y, s
+    for scale in (1.0, 0.5):                 # replay on new data written into the captured input buffer
+        static_x.copy_(x * scale)
+        graph.replay()
+        torch.cuda.synchronize()
+        xs = (x * scale)
+        s_ref, o_ref = O.minmax_tensor(xs.cpu().contiguous(), 8, False)
+        assert float(outs["s"]) == float(s_ref)
+        y_ref = O.fq_zeropoint(xs.cpu().contiguous(), s_ref, o_ref, 0, 255)[1]
+        assert_bits_equal(outs["y"].contiguous(), y_ref, f"graph replay scale {scale}")
+        eager = torch.nn.functional.conv2d(outs["y"], O.fq_symmetric(w.cpu(), s_w.cpu(), -127, 127)[1].to(DEV), padding=1)
+        torch.testing.assert_close(outs["conv"], eager, rtol=1e-4, atol=1e-4)
