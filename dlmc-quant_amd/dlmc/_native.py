@@ -66,6 +66,13 @@ def _load():
 lib = _load()
 
 
+def experimental(name, argtypes):
+    """A symbol exported by the library but deliberately absent from include/dlmcq.h (tests / tuning only)."""
+    fn = getattr(lib, name)
+    fn.restype, fn.argtypes = ctypes.c_int, argtypes
+    return fn
+
+
 class DlmcqError(RuntimeError):
     pass
 

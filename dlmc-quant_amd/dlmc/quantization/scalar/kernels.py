@@ -257,7 +257,7 @@ def quantize_weight_krsc(w, scale, lo, hi):
     return wq, wsum
 
 
-def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1):
+def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1, variant=None):
     """Fused int8 conv / linear on the matrix cores.  `codes`: uint8/int8 activation codes, logically
     (N, C, H, W) in channels_last memory, or (N, C) for a linear layer.  Returns fp32 (N, K, P, Q) in
     channels_last memory (or (N, K))."""
@@ -285,9 +285,13 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
     in_zp = None if in_zp is None else _f32c(in_zp, out).reshape(-1)
     bias = None if bias is None else bias.detach().contiguous()
     macs = n * P * Q * K * R * S * c
-    PROFILE.launch("conv_i8", codes.numel() + out.numel() * 4 + wq.numel(), lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(
-        N.ptr(codes), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),
-        n, h, w_, c, K, R, S, int(stride), int(padding), int(dilation), int(codes.dtype == torch.uint8), N.stream_ptr())))
+    args = (N.ptr(codes), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),
+            n, h, w_, c, K, R, S, int(stride), int(padding), int(dilation), int(codes.dtype == torch.uint8), N.stream_ptr())
+    if variant is None:
+        PROFILE.launch("conv_i8", codes.numel() + out.numel() * 4 + wq.numel(),
+                       lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(*args)))
+    else:   # test / tuning hook outside the ABI
+        N.check(N.experimental("dlmcq_x_conv2d_i8_variant", N.SIGNATURES["dlmcq_conv2d_i8_nhwc_f32"][1] + [N._i32])(*args, int(variant)))
     return out
 
 
