@@ -188,19 +188,22 @@ __device__ const PadTable g_pad_table = PadTable();
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN>
+template <int BM, int BN, int NBUF = 3, int BK = CV_BK>
 __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                          float* __restrict__ out, const float* __restrict__ bias,
                                                          const int32_t* __restrict__ wsum,
                                                          const float* __restrict__ s_in,
                                                          const float* __restrict__ zp_in,
                                                          const float* __restrict__ s_w, ConvGeom g, int shift) {
-  constexpr int NBUF = 3;
-  constexpr int TILE_A = BM * CV_BK, TILE_B = BN * CV_BK, TILE = TILE_A + TILE_B;
+  constexpr int PF = NBUF - 1;  // K steps in flight
+  constexpr int TILE_A = BM * BK, TILE_B = BN * BK, TILE = TILE_A + TILE_B;
   constexpr int MT = BM / 128;  // 32-row slabs per wave along M (a wave owns BM/4 consecutive rows)
   constexpr int NT = BN / 32;
-  constexpr int AI = BM / 64;   // A wave-instructions per wave per step (16 rows each)
-  constexpr int BI = BN / 64;   // B wave-instructions per wave per step
+  constexpr int SLOTS = BK / 16;        // 16-byte slots per LDS row (one row = BK bytes = one full 64/128-B line)
+  constexpr int RPI = 64 / SLOTS;       // tile rows covered by one wave-instruction (1 KiB)
+  constexpr int RPB = 256 / BK;         // tile rows per 256-byte LDS bank row: the swizzle key is row / RPB
+  constexpr int AI = BM / (RPI * 4);    // A wave-instructions per wave per step
+  constexpr int BI = BN / (RPI * 4);    // B wave-instructions per wave per step
   __shared__ __attribute__((aligned(1024))) int8_t lds[NBUF * TILE];
 
   const uint32_t nwg = gridDim.x;
@@ -218,13 +221,13 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
   const uint32_t xorw = shift ? 0x80808080u : 0u;
 
   // ---- DMA assignment: wave-instruction i of this wave covers tile rows (i*4 + wave)*16 .. +15 ----
-  const int lrow = lane >> 2, pslot = lane & 3;
+  const int lrow = lane / SLOTS, pslot = lane % SLOTS;
   int a_n[AI], a_h0[AI], a_w0[AI], a_seg[AI];
   bool a_ok[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int row = (i * 4 + wave) * 16 + lrow;
-    a_seg[i] = pslot ^ ((row >> 2) & 3);
+    const int row = (i * 4 + wave) * RPI + lrow;
+    a_seg[i] = pslot ^ ((row / RPB) & (SLOTS - 1));
     const int64_t m = m0 + row;
     a_ok[i] = m < g.M;
     const int64_t mm = a_ok[i] ? m : 0;
@@ -240,12 +243,12 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
   const int64_t wrow = (int64_t)g.R * g.S * g.C;
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int row = (i * 4 + wave) * 16 + lrow;
-    b_seg[i] = pslot ^ ((row >> 2) & 3);
+    const int row = (i * 4 + wave) * RPI + lrow;
+    b_seg[i] = pslot ^ ((row / RPB) & (SLOTS - 1));
     const int k = n0 + row;
     b_src[i] = k < g.K ? w + (int64_t)k * wrow : nullptr;
   }
-  const int cchunks = g.C / CV_BK;
+  const int cchunks = g.C / BK;
   const int nsteps = g.R * g.S * cchunks;
 
   int f_cc = 0, f_s = 0, f_r = 0, f_buf = 0;
@@ -257,12 +260,12 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
       const int h = a_h0[i] + f_r * g.dil, ww = a_w0[i] + f_s * g.dil;
       const int8_t* src = padline;
       if (a_ok[i] && h >= 0 && h < g.H && ww >= 0 && ww < g.W)
-        src = x + (((int64_t)a_n[i] * g.H + h) * g.W + ww) * g.C + f_cc * CV_BK + a_seg[i] * 16;
+        src = x + (((int64_t)a_n[i] * g.H + h) * g.W + ww) * g.C + f_cc * BK + a_seg[i] * 16;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int8_t* src = b_src[i] ? b_src[i] + (int64_t)rs * g.C + f_cc * CV_BK + b_seg[i] * 16 : g_pad_table.b;
+      const int8_t* src = b_src[i] ? b_src[i] + (int64_t)rs * g.C + f_cc * BK + b_seg[i] * 16 : g_pad_table.b;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + TILE_A + (i * 4 + wave) * 1024), 16, 0, 0);
     }
     if (++f_cc == cchunks) {
@@ -285,36 +288,42 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
 
   const int wrow0 = wave * (BM / 4);            // first tile row of this wave
   const int hsel = lane >> 5;
-  issue();
-  if (nsteps > 1) issue();
+#pragma unroll
+  for (int i = 0; i < PF; ++i)
+    if (i < nsteps) issue();
   int c_buf = 0;
   for (int step = 0; step < nsteps; ++step) {
     // step's own DMAs must have landed; the next step's group (AI + BI instructions) may stay in flight
-    if (step + 1 < nsteps) {
-      if (AI + BI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else if (AI + BI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (AI + BI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (step + PF - 1 < nsteps) {                 // PF-1 younger groups stay in flight
+      constexpr int KEEP = (PF - 1) * (AI + BI);
+      if (KEEP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (KEEP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (KEEP == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if (KEEP == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (KEEP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: drain (conservative)
     }
     __builtin_amdgcn_s_barrier();                 // everyone's step-k bytes are in LDS; everyone left multiply(k-1)
-    if (step + 2 < nsteps) issue();               // into the buffer multiply(k-1) just released
+    if (step + PF < nsteps) issue();              // into the buffer multiply(k-1) just released
     const int8_t* base = lds + c_buf * TILE;
 #pragma unroll
-    for (int ks = 0; ks < CV_BK / 32; ++ks) {
+    for (int ks = 0; ks < BK / 32; ++ks) {
       const int sg = ks * 2 + hsel;
       i32x4 af[MT];
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
         const int arow = wrow0 + mi * 32 + (lane & 31);
-        const i32x4 t = *reinterpret_cast<const i32x4*>(base + arow * 64 + ((sg ^ ((arow >> 2) & 3)) << 4));
+        const i32x4 t = *reinterpret_cast<const i32x4*>(base + arow * BK + ((sg ^ ((arow / RPB) & (SLOTS - 1))) << 4));
         af[mi] = i32x4{(int)(t.x ^ xorw), (int)(t.y ^ xorw), (int)(t.z ^ xorw), (int)(t.w ^ xorw)};
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int brow = j * 32 + (lane & 31);
-        const i32x4 bf = *reinterpret_cast<const i32x4*>(base + TILE_A + brow * 64 + ((sg ^ ((brow >> 2) & 3)) << 4));
+        const i32x4 bf = *reinterpret_cast<const i32x4*>(base + TILE_A + brow * BK + ((sg ^ ((brow / RPB) & (SLOTS - 1))) << 4));
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) acc[mi][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[mi], bf, acc[mi][j], 0, 0, 0);
       }
@@ -598,7 +607,8 @@ extern "C" int dlmcq_conv2d_i8_nhwc_f32(const void* x, const int8_t* w, float* o
 
 // NOT part of the ABI (absent from include/dlmcq.h): the same call with an explicit kernel variant, for the tests and
 // for A/B measurements in one process.  0 register-staged, 1 LDS-DMA (default), 3 LDS-DMA with 256-row tiles where
-// eligible, 4 wave-specialised loader/consumer.
+// eligible, 4 wave-specialised loader/consumer.  (Deeper rings - 4 / 5 LDS buffers - and 128-byte K steps were also
+// measured through the NBUF / BK template parameters and lost 5-40 %: occupancy matters more here)
 extern "C" int dlmcq_x_conv2d_i8_variant(const void* x, const int8_t* w, float* out, const float* bias,
                                          const int32_t* wsum, const float* in_scale, const float* in_zero_point,
                                          const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
