@@ -314,6 +314,27 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void dequant_kernel(const void* __rest
   }
 }
 
+// Fast path of the dequantisation: int8 codes, 4 per lane (one dword in, one dwordx4 out), when four consecutive
+// elements always share a channel (per tensor, or inner % 4 == 0) and the buffers are aligned.
+template <int FORM>
+__global__ __launch_bounds__(DLMCQ_WAVE) void dequant_i8_vec_kernel(const uint32_t* __restrict__ codes, f32x4* __restrict__ y,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ offset, int64_t n4,
+                                                                   int64_t channels, int64_t inner4, int is_signed, float g) {
+  for (int64_t i = (int64_t)blockIdx.x * DLMCQ_WAVE + threadIdx.x; i < n4; i += (int64_t)gridDim.x * DLMCQ_WAVE) {
+    const uint32_t w = __builtin_nontemporal_load(codes + i);
+    const int64_t ch = channels == 1 ? 0 : (i / inner4) % channels;
+    const ChanConst<FORM> c(scale[ch], offset ? offset[ch] : 0.0f, g, 0.0f, 0.0f);
+    float q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t b = (w >> (8 * j)) & 0xffu;
+      q[j] = is_signed ? (float)(int8_t)b : (float)b;
+    }
+    __builtin_nontemporal_store(f32x4{dq_one<FORM>(q[0], c), dq_one<FORM>(q[1], c), dq_one<FORM>(q[2], c), dq_one<FORM>(q[3], c)}, y + i);
+  }
+}
+
 // ------------------------------------------------------------------------------- host side
 static int blocks_for(int64_t work_items, int per_block, int max_blocks) {
   int64_t b = (work_items + per_block - 1) / per_block;
@@ -380,6 +401,25 @@ static int launch_fq(const float* x, const FqOut& out, const float* scale, const
 template <int SRC>
 static int launch_dq(const void* src, float* y, const float* scale, const float* offset, int64_t n, int64_t channels,
                      int64_t inner, int form, int is_signed, float g, hipStream_t st) {
+  if (SRC == 1 && (n & 3) == 0 && (channels == 1 || (inner & 3) == 0) && aligned4(src) && aligned16(y)) {
+    const int64_t n4 = n >> 2;
+    const int vgrid = blocks_for(n4, DLMCQ_WAVE, 1 << 24);
+    const uint32_t* cs = reinterpret_cast<const uint32_t*>(src);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+#define DLMCQ_DQV(F)                                                                                                   \
+  hipLaunchKernelGGL((dequant_i8_vec_kernel<F>), dim3(vgrid), dim3(DLMCQ_WAVE), 0, st, cs, y4, scale, offset, n4, channels, \
+                     inner >> 2, is_signed, g)
+    switch (form) {
+      case DLMCQ_FORM_EMULATE: DLMCQ_DQV(DLMCQ_FORM_EMULATE); break;
+      case DLMCQ_FORM_QBASE: DLMCQ_DQV(DLMCQ_FORM_QBASE); break;
+      case DLMCQ_FORM_ZEROPOINT: DLMCQ_DQV(DLMCQ_FORM_ZEROPOINT); break;
+      case DLMCQ_FORM_SYMMETRIC: DLMCQ_DQV(DLMCQ_FORM_SYMMETRIC); break;
+      case DLMCQ_FORM_ROOTQ_ACT: DLMCQ_DQV(DLMCQ_FORM_ROOTQ_ACT); break;
+      default: return DLMCQ_EINVAL;
+    }
+#undef DLMCQ_DQV
+    return launch_status();
+  }
   const int grid = blocks_for((n + 1) / 2, DLMCQ_BLOCK, DLMCQ_CUS * 32);
 #define DLMCQ_DQ(F)                                                                                               \
   hipLaunchKernelGGL((dequant_kernel<F, SRC>), dim3(grid), dim3(DLMCQ_BLOCK), 0, st, src, y, scale, offset, n, \

@@ -5,7 +5,7 @@
 // Specification = what autograd executes through modules/base.py:96-102 (closed form in
 // modules/function.py:37-49); with v = (x - o)/s^ and inside = [lo <= v <= hi]:
 //   gx    = inside ? (gy * s^) / s^ : +0          (two roundings - identical to autograd's mul, div)
-//   gs[c] = g * sum( gy*q - inside*(gy*s^)*(v/s^) ),   q = ste_round(clamp(v))
+//   gs[c] = g * sum( gy*(q - inside*v) ),               q = ste_round(clamp(v))      (= LSQ's closed form)
 #include "dlmcq_internal.h"
 
 namespace dlmcq {
@@ -22,8 +22,10 @@ __device__ __forceinline__ void bwd_one(float x, float gy, const BwdConst& c, fl
   const float q = ste_round(clamp_nan(v, lo, hi));
   const bool inside = (v >= lo) && (v <= hi);
   const float gv = inside ? gy * c.sh : 0.0f;
-  gx = gv / c.sh;
-  contrib = gy * q + (-gv) * (v / c.sh);
+  gx = gv / c.sh;                               // bit-exact with autograd's mul-then-div
+  // autograd accumulates gy*q and -gv*(v/s^) separately; gv*(v/s^) == gy*v up to rounding and the scale
+  // gradient is an order-dependent sum anyway, so the third division is not spent: gy*(q - [inside]*v)
+  contrib = gy * (q - (inside ? v : 0.0f));
 }
 
 __device__ __forceinline__ float wave_sum(float s) {
@@ -152,8 +154,23 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void fq_bwd_finalize_kernel(const floa
   gscale[c] = (float)s * g;
 }
 
-constexpr int BWD_U = 2;
-constexpr int BWD_TENSOR_BLOCKS = DLMCQ_CUS * 8;
+// Per tensor: one block folds all workgroup partials (strided fp64 sums, then a tree through LDS).
+__global__ __launch_bounds__(DLMCQ_BLOCK) void fq_bwd_finalize_tensor_kernel(const float* __restrict__ partials, int64_t n,
+                                                                            float g, float* __restrict__ gscale) {
+  __shared__ double red[DLMCQ_BLOCK];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += DLMCQ_BLOCK) s += (double)partials[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = DLMCQ_BLOCK / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gscale[0] = (float)red[0] * g;
+}
+
+constexpr int BWD_U = 1;                      // one float4 of x and of gy per lane, one chunk per workgroup
+constexpr int BWD_TENSOR_BLOCKS = 8192;       // persistent grid: one partial sum per workgroup for the finalize to fold
 
 struct BwdPlan {
   int64_t nseg;   // partial rows
@@ -227,6 +244,10 @@ extern "C" int dlmcq_fake_quant_bwd_f32(const float* x, const float* gy, float* 
   }
   int rc = launch_status();
   if (rc != DLMCQ_OK || !gscale) return rc;
+  if (channels == 1) {
+    hipLaunchKernelGGL(fq_bwd_finalize_tensor_kernel, dim3(1), dim3(DLMCQ_BLOCK), 0, st, part, p.nseg, ste_g, gscale);
+    return launch_status();
+  }
   const int g = (int)((channels + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK);
   hipLaunchKernelGGL(fq_bwd_finalize_kernel, dim3(g), dim3(DLMCQ_BLOCK), 0, st, part, p.nseg, channels, ste_g, gscale);
   return launch_status();

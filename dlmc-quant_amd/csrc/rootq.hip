@@ -21,24 +21,24 @@ __device__ __forceinline__ float rootq_w_one(float w, float up, float lw, float 
 }
 
 template <int U>
-__global__ __launch_bounds__(DLMCQ_BLOCK) void rootq_weight_kernel(const float* w, float* y,
+__global__ __launch_bounds__(DLMCQ_WAVE) void rootq_weight_kernel(const float* w, float* y,
                                                                   const float* __restrict__ bounds, int64_t n,
                                                                   float range, int vec) {
   const float up = bounds[0], lw = bounds[1];
   const float delta = (up - lw) / range;
   const int64_t n4 = vec ? (n >> 2) : 0;
-  const int64_t nchunks = (n4 + DLMCQ_BLOCK * U - 1) / (DLMCQ_BLOCK * U);
+  const int64_t nchunks = (n4 + DLMCQ_WAVE * U - 1) / (DLMCQ_WAVE * U);
   for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int64_t i0 = chunk * (DLMCQ_BLOCK * U) + threadIdx.x;
+    const int64_t i0 = chunk * (DLMCQ_WAVE * U) + threadIdx.x;
     f32x4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * DLMCQ_BLOCK;
+      const int64_t i = i0 + u * DLMCQ_WAVE;
       if (i < n4) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w) + i);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * DLMCQ_BLOCK;
+      const int64_t i = i0 + u * DLMCQ_WAVE;
       if (i < n4) {
         f32x4 o;
         o.x = rootq_w_one(v[u].x, up, lw, delta);
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void rootq_weight_kernel(const float* 
       }
     }
   }
-  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * DLMCQ_BLOCK + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * DLMCQ_BLOCK)
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * DLMCQ_WAVE + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * DLMCQ_WAVE)
     y[i] = rootq_w_one(w[i], up, lw, delta);
 }
 
@@ -63,12 +63,12 @@ extern "C" int dlmcq_rootq_weight_f32(const float* w, float* y, const float* bou
   if (n < 0 || lo >= hi) return DLMCQ_EINVAL;
   if (n == 0) return DLMCQ_OK;
   if (!w || !y || !bounds) return DLMCQ_EINVAL;
-  constexpr int U = 4;
+  constexpr int U = 1;   // one-wave workgroups, one float4 per lane (the fake-quant kernels' measured optimum)
   const int vec = aligned16(w) && aligned16(y);
-  int64_t b = ((n >> 2) + DLMCQ_BLOCK * U - 1) / (DLMCQ_BLOCK * U);
+  int64_t b = ((n >> 2) + DLMCQ_WAVE * U - 1) / (DLMCQ_WAVE * U);
   if (b < 1) b = 1;
-  if (b > DLMCQ_CUS * 16) b = DLMCQ_CUS * 16;
-  hipLaunchKernelGGL((rootq_weight_kernel<U>), dim3((int)b), dim3(DLMCQ_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+  if (b > (1 << 24)) b = 1 << 24;
+  hipLaunchKernelGGL((rootq_weight_kernel<U>), dim3((int)b), dim3(DLMCQ_WAVE), 0, reinterpret_cast<hipStream_t>(stream),
                      w, y, bounds, n, (float)(hi - lo), vec);
   return launch_status();
 }

@@ -86,6 +86,25 @@ def main():
     rec("observer A per-channel(ax1) minmax (1R)", 4 * nA, lambda: K.observe_qparams(A, 8, False, ch_axis=1))
     rec("observer W per-channel(ax0) absmax (1R)", 4 * nW, lambda: K.observe_qparams(W, 8, True, ch_axis=0))
 
+    gy = torch.randn_like(A)
+    gx = torch.empty_like(A)
+
+    def bwd():
+        from dlmc import _native as NN
+        sc = K._scratch(NN.lib.dlmcq_fq_bwd_scratch_bytes(1, 1, nA), A.device)
+        gs = torch.empty(1, device=dev)
+        NN.check(NN.lib.dlmcq_fake_quant_bwd_f32(NN.ptr(A), NN.ptr(gy), NN.ptr(gx), NN.ptr(gs), NN.ptr(s_t.reshape(1)), NN.ptr(o_t.reshape(1)),
+                                                 1, 1, nA, -127, 127, g, NN.ptr(sc), sc.numel() * 4, NN.stream_ptr()))
+    rec("fq backward A per-tensor QBASE (2R+1W + scale grad)", 12 * nA, bwd)
+    up, lw = torch.tensor(2.5, device=dev), torch.tensor(-2.5, device=dev)
+    rec("rootq weight forward on A-sized tensor (1R+1W)", 8 * nA, lambda: K.rootq_weight(A, up, lw, 0, 15))
+    _, codes8 = K.fake_quant(A, s_t, o_t, -127, 127, N.FORM_QBASE, g=g, codes="i8", want_y=False)
+    rec("dequant int8 codes -> fp32 (1 B R + 4 B W)", 5 * nA, lambda: K.dequant_codes(codes8, A.shape, s_t, o_t, N.FORM_QBASE, "i8", True, g=g))
+    c4 = torch.randint(0, 16, (nA,), dtype=torch.int8, device=dev)
+    rec("pack int4 (1 B R + 0.5 B W)", int(1.5 * nA), lambda: K.pack_int4(c4))
+    p4 = K.pack_int4(c4)
+    rec("unpack int4 (0.5 B R + 1 B W)", int(1.5 * nA), lambda: K.unpack_int4(p4, nA, False))
+
     def obs_fq():
         s, o = K.observe_qparams(A, 8, True)
         K.fake_quant(A, s, o, -127, 127, N.FORM_QBASE, g=g, out=out)
