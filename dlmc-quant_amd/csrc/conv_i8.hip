@@ -188,7 +188,8 @@ __device__ const PadTable g_pad_table = PadTable();
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int NBUF = 3, int BK = CV_BK>
+// ABL (timing-only ablations, never shipped): 1 = no operand DMA inside the K loop, 2 = no MFMA, 4 = no LDS fragment reads
+template <int BM, int BN, int NBUF = 3, int BK = CV_BK, int ABL = 0>
 __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                          float* __restrict__ out, const float* __restrict__ bias,
                                                          const int32_t* __restrict__ wsum,
@@ -294,7 +295,9 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
   int c_buf = 0;
   for (int step = 0; step < nsteps; ++step) {
     // step's own DMAs must have landed; the next step's group (AI + BI instructions) may stay in flight
-    if (step + PF - 1 < nsteps) {                 // PF-1 younger groups stay in flight
+    if (ABL & 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (step + PF - 1 < nsteps) {          // PF-1 younger groups stay in flight
       constexpr int KEEP = (PF - 1) * (AI + BI);
       if (KEEP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else if (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: drain (conservative)
     }
     __builtin_amdgcn_s_barrier();                 // everyone's step-k bytes are in LDS; everyone left multiply(k-1)
-    if (step + PF < nsteps) issue();              // into the buffer multiply(k-1) just released
+    if (!(ABL & 1) && step + PF < nsteps) issue();  // into the buffer multiply(k-1) just released
     const int8_t* base = lds + c_buf * TILE;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
@@ -317,21 +320,70 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
         const int arow = wrow0 + mi * 32 + (lane & 31);
-        const i32x4 t = *reinterpret_cast<const i32x4*>(base + arow * BK + ((sg ^ ((arow / RPB) & (SLOTS - 1))) << 4));
+        const i32x4 t = (ABL & 4) ? i32x4{lane, step, ks, mi}
+                                  : *reinterpret_cast<const i32x4*>(base + arow * BK + ((sg ^ ((arow / RPB) & (SLOTS - 1))) << 4));
         af[mi] = i32x4{(int)(t.x ^ xorw), (int)(t.y ^ xorw), (int)(t.z ^ xorw), (int)(t.w ^ xorw)};
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int brow = j * 32 + (lane & 31);
-        const i32x4 bf = *reinterpret_cast<const i32x4*>(base + TILE_A + brow * BK + ((sg ^ ((brow / RPB) & (SLOTS - 1))) << 4));
+        const i32x4 bf = (ABL & 4) ? i32x4{j, lane, step, ks}
+                                   : *reinterpret_cast<const i32x4*>(base + TILE_A + brow * BK + ((sg ^ ((brow / RPB) & (SLOTS - 1))) << 4));
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) acc[mi][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[mi], bf, acc[mi][j], 0, 0, 0);
+        for (int mi = 0; mi < MT; ++mi) {
+          if (ABL & 2) {
+            asm volatile("" ::"v"(af[mi]), "v"(bf));      // keep the fragments live without multiplying
+            acc[mi][j][0] += bf.x;
+          } else {
+            acc[mi][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[mi], bf, acc[mi][j], 0, 0, 0);
+          }
+        }
       }
     }
     if (++c_buf == NBUF) c_buf = 0;
   }
 
   const float sin = s_in[0];
+  if (MT == 1 && (g.K & 3) == 0) {
+    // ---- epilogue through LDS: accumulator layout (lane = channel, register = row) -> row-major, so that each
+    // lane stores 16 B and each wave-instruction writes 4 rows x 256 contiguous bytes: 16 dwordx4 stores per lane
+    // instead of 64 dword stores (the 1x1 layers are bound by this output stream).  Two passes of 64 channels. ----
+    constexpr int EP_LD = 68;                       // floats per staged row (64 + 4 pad)
+    __builtin_amdgcn_s_barrier();                   // every wave is done reading the operand buffers
+    float* stg = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
+    static_assert(4 * 32 * EP_LD * 4 <= NBUF * TILE, "epilogue staging must fit the operand buffers");
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+#pragma unroll
+    for (int h = 0; h < NT / 2 + (NT & 1); ++h) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = h * 2 + jj;
+        if (j >= NT) continue;
+        const int col = n0 + j * 32 + (lane & 31);
+        const bool cok = col < g.K;
+        const float mult = cok ? sin * s_w[col] : 0.0f;
+        const int corr = cok ? (shift - zpi) * wsum[col] : 0;
+        const float bv = (cok && bias) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+          stg[r * EP_LD + jj * 32 + (lane & 31)] = (float)(acc[0][j][i] + corr) * mult + bv;
+        }
+      }
+      // a wave only reads back what it wrote itself: no block barrier, just the LDS counter
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int col = n0 + h * 64 + ec;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = it * 4 + er;
+        const int64_t row = m0 + wrow0 + r;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * EP_LD + ec);
+        if (row < g.M && col < g.K) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + row * g.K + col));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the stage
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + j * 32 + (lane & 31);
@@ -584,6 +636,16 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   } else if (variant == 0) {
     if (bnn == 64) hipLaunchKernelGGL((conv_i8_kernel<64>), DLMCQ_CONV_ARGS);
     else hipLaunchKernelGGL((conv_i8_kernel<128>), DLMCQ_CONV_ARGS);
+  } else if (variant >= 10 && variant <= 17 && bnn == 128) {   // timing-only ablations (wrong results by design)
+    switch (variant - 10) {
+      case 1: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 1>), DLMCQ_CONV_ARGS); break;
+      case 2: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 2>), DLMCQ_CONV_ARGS); break;
+      case 4: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 4>), DLMCQ_CONV_ARGS); break;
+      case 6: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 6>), DLMCQ_CONV_ARGS); break;
+      case 5: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 5>), DLMCQ_CONV_ARGS); break;
+      case 3: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 3>), DLMCQ_CONV_ARGS); break;
+      default: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 7>), DLMCQ_CONV_ARGS); break;
+    }
   } else if (bmm == 256) {
     hipLaunchKernelGGL((conv_i8_dma_kernel<256, 128>), DLMCQ_CONV_ARGS);
   } else if (bnn == 64) {
