@@ -344,14 +344,14 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
   }
 
   const float sin = s_in[0];
-  if (MT == 1 && (g.K & 3) == 0) {
+  constexpr bool EP_FITS = 4 * 32 * 68 * 4 <= NBUF * TILE;   // the LDS epilogue stage re-uses the operand buffers
+  if (MT == 1 && EP_FITS && (g.K & 3) == 0) {
     // ---- epilogue through LDS: accumulator layout (lane = channel, register = row) -> row-major, so that each
     // lane stores 16 B and each wave-instruction writes 4 rows x 256 contiguous bytes: 16 dwordx4 stores per lane
     // instead of 64 dword stores (the 1x1 layers are bound by this output stream).  Two passes of 64 channels. ----
     constexpr int EP_LD = 68;                       // floats per staged row (64 + 4 pad)
     __builtin_amdgcn_s_barrier();                   // every wave is done reading the operand buffers
     float* stg = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
-    static_assert(4 * 32 * EP_LD * 4 <= NBUF * TILE, "epilogue staging must fit the operand buffers");
     const int er = lane >> 4, ec = (lane & 15) * 4;
 #pragma unroll
     for (int h = 0; h < NT / 2 + (NT & 1); ++h) {
