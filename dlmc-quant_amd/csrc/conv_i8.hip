@@ -262,12 +262,12 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
       const int8_t* src = padline;
       if (a_ok[i] && h >= 0 && h < g.H && ww >= 0 && ww < g.W)
         src = x + (((int64_t)a_n[i] * g.H + h) * g.W + ww) * g.C + f_cc * BK + a_seg[i] * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
+      if (!(ABL & 8)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int8_t* src = b_src[i] ? b_src[i] + (int64_t)rs * g.C + f_cc * BK + b_seg[i] * 16 : g_pad_table.b;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + TILE_A + (i * 4 + wave) * 1024), 16, 0, 0);
+      if (!(ABL & 16)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + TILE_A + (i * 4 + wave) * 1024), 16, 0, 0);
     }
     if (++f_cc == cchunks) {
       f_cc = 0;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
   int c_buf = 0;
   for (int step = 0; step < nsteps; ++step) {
     // step's own DMAs must have landed; the next step's group (AI + BI instructions) may stay in flight
-    if (ABL & 1) {
+    if (ABL & (1 | 8 | 16 | 32)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (step + PF - 1 < nsteps) {          // PF-1 younger groups stay in flight
       constexpr int KEEP = (PF - 1) * (AI + BI);
@@ -547,6 +547,212 @@ __global__ __launch_bounds__(512) void conv_i8_ws_kernel(const int8_t* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 256-row wave-specialised kernel for the layers with a long reduction (3x3 taps, many input channels), where
+// the ablations above show the operand stream - not the matrix cores - setting the pace.  One workgroup per CU:
+//   8 consumer waves (MFMA + ds_read only), arranged (8/WN) x WN with WN = BN/64, each owning a (256*WN/8) x 64
+//   output slab; 4 loader waves (global_load_lds only) feeding a 3-buffer ring of (256 + BN) x 64-byte tiles.
+// Versus the 128 x 128 tile this halves (BN = 256) the operand bytes per MAC, and the loaders' DMA issue runs
+// beside the consumers' MFMAs instead of in front of them.  Same hand-off as above: loaders wait (counted vmcnt)
+// for step k, one s_barrier per step joined by all 12 waves, loaders refill the buffer step k-1 released.
+template <int BN, int NBUF = 3>
+__global__ __launch_bounds__(768) void conv_i8_ws256_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                           float* __restrict__ out, const float* __restrict__ bias,
+                                                           const int32_t* __restrict__ wsum,
+                                                           const float* __restrict__ s_in,
+                                                           const float* __restrict__ zp_in,
+                                                           const float* __restrict__ s_w, ConvGeom g, int shift) {
+  constexpr int BM = 256, PF = NBUF - 1;
+  constexpr int TILE_A = BM * CV_BK, TILE_B = BN * CV_BK, TILE = TILE_A + TILE_B;
+  constexpr int WN = BN / 64, WM = 8 / WN;      // consumer grid
+  constexpr int WROWS = BM / WM, MT = WROWS / 32, NT = 2;
+  constexpr int AI = BM / 64, BI = BN / 64;     // DMA wave-instructions per LOADER wave per step (16 rows each)
+  constexpr int EP_LD = 68;                     // floats per staged epilogue row (64 + 4 pad)
+  constexpr int EP_BYTES = 8 * 32 * EP_LD * 4;  // the epilogue stage re-uses the operand ring
+  constexpr int LDS_BYTES = NBUF * TILE > EP_BYTES ? NBUF * TILE : EP_BYTES;
+  __shared__ __attribute__((aligned(1024))) int8_t lds[LDS_BYTES];
+
+  const uint32_t nwg = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t qd = nwg >> 3, rm = nwg & 7u;
+  const uint32_t tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
+  const int bn = tile % g.nblk_n, bm = tile / g.nblk_n;
+  const int64_t m0 = (int64_t)bm * BM;
+  const int n0 = bn * BN;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float zpf = zp_in ? zp_in[0] : 0.0f;
+  const int zpi = (int)__builtin_rintf(zpf);
+  const int cchunks = g.C / CV_BK;
+  const int nsteps = g.R * g.S * cchunks;
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = wave - 8;
+    const int8_t* padline = g_pad_table.b + ((zpi & 0xff) << 4);
+    const int lrow = lane >> 2, pslot = lane & 3;
+    int a_n[AI], a_h0[AI], a_w0[AI], a_seg[AI];
+    bool a_ok[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int row = (i * 4 + lw) * 16 + lrow;
+      a_seg[i] = pslot ^ ((row >> 2) & 3);
+      const int64_t m = m0 + row;
+      a_ok[i] = m < g.M;
+      const int64_t mm = a_ok[i] ? m : 0;
+      const int q = (int)(mm % g.Q);
+      const int64_t t = mm / g.Q;
+      const int p = (int)(t % g.P);
+      a_n[i] = (int)(t / g.P);
+      a_h0[i] = p * g.stride - g.pad;
+      a_w0[i] = q * g.stride - g.pad;
+    }
+    int b_seg[BI];
+    const int8_t* b_src[BI];
+    const int64_t wrow = (int64_t)g.R * g.S * g.C;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int row = (i * 4 + lw) * 16 + lrow;
+      b_seg[i] = pslot ^ ((row >> 2) & 3);
+      const int k = n0 + row;
+      b_src[i] = k < g.K ? w + (int64_t)k * wrow : nullptr;
+    }
+    int f_cc = 0, f_s = 0, f_r = 0, f_buf = 0;
+    auto issue = [&]() {
+      int8_t* base = lds + f_buf * TILE;
+      const int rs = f_r * g.S + f_s;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int h = a_h0[i] + f_r * g.dil, ww = a_w0[i] + f_s * g.dil;
+        const int8_t* src = padline;
+        if (a_ok[i] && h >= 0 && h < g.H && ww >= 0 && ww < g.W)
+          src = x + (((int64_t)a_n[i] * g.H + h) * g.W + ww) * g.C + f_cc * CV_BK + a_seg[i] * 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * 4 + lw) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        const int8_t* src = b_src[i] ? b_src[i] + (int64_t)rs * g.C + f_cc * CV_BK + b_seg[i] * 16 : g_pad_table.b;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + TILE_A + (i * 4 + lw) * 1024), 16, 0, 0);
+      }
+      if (++f_cc == cchunks) {
+        f_cc = 0;
+        if (++f_s == g.S) {
+          f_s = 0;
+          ++f_r;
+        }
+      }
+      if (++f_buf == NBUF) f_buf = 0;
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (i < nsteps) issue();
+    for (int step = 0; step < nsteps; ++step) {
+      if (step + PF - 1 < nsteps) {   // keep the PF-1 younger steps' instructions in flight
+        constexpr int KEEP = (PF - 1) * (AI + BI);
+        if (KEEP == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (KEEP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (KEEP == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (KEEP == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (KEEP == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else if (KEEP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (KEEP == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (KEEP == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if (KEEP == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (KEEP == 30) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (step + PF < nsteps) issue();
+    }
+    __builtin_amdgcn_s_barrier();   // pairs with the consumers' pre-epilogue barrier
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer waves
+  const uint32_t xorw = shift ? 0x80808080u : 0u;
+  const int wm = wave / WN, wn = wave % WN;
+  const int wrow0 = wm * WROWS, wcol0 = wn * 64;
+  i32x16 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][j][i] = 0;
+  const int hsel = lane >> 5;
+  int c_buf = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    __builtin_amdgcn_s_barrier();
+    const int8_t* base = lds + c_buf * TILE;
+#pragma unroll
+    for (int ks = 0; ks < CV_BK / 32; ++ks) {
+      const int sg = ks * 2 + hsel;
+      i32x4 bf[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int brow = wcol0 + j * 32 + (lane & 31);
+        bf[j] = *reinterpret_cast<const i32x4*>(base + TILE_A + brow * 64 + ((sg ^ ((brow >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int arow = wrow0 + mi * 32 + (lane & 31);
+        i32x4 af = *reinterpret_cast<const i32x4*>(base + arow * 64 + ((sg ^ ((arow >> 2) & 3)) << 4));
+        af = i32x4{(int)(af.x ^ xorw), (int)(af.y ^ xorw), (int)(af.z ^ xorw), (int)(af.w ^ xorw)};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[mi][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], acc[mi][j], 0, 0, 0);
+      }
+    }
+    if (++c_buf == NBUF) c_buf = 0;
+  }
+
+  // ---- epilogue through LDS (per wave: 32 rows x 64 channels per pass), dwordx4 stores of 256 contiguous bytes ----
+  __builtin_amdgcn_s_barrier();                     // all consumers are done with the operand ring
+  float* stg = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
+  const float sin = s_in[0];
+  const int er = lane >> 4, ec = (lane & 15) * 4;
+  float mult[NT], bv[NT];
+  int corr[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wcol0 + j * 32 + (lane & 31);
+    const bool cok = col < g.K;
+    mult[j] = cok ? sin * s_w[col] : 0.0f;
+    corr[j] = cok ? (shift - zpi) * wsum[col] : 0;
+    bv[j] = (cok && bias) ? bias[col] : 0.0f;
+  }
+  const bool vec_ok = (g.K & 3) == 0;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        stg[r * EP_LD + j * 32 + (lane & 31)] = (float)(acc[mi][j][i] + corr[j]) * mult[j] + bv[j];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int col = n0 + wcol0 + ec;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 4 + er;
+      const int64_t row = m0 + wrow0 + mi * 32 + r;
+      if (row >= g.M) continue;
+      if (vec_ok) {
+        if (col < g.K)
+          __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(stg + r * EP_LD + ec),
+                                      reinterpret_cast<f32x4*>(out + row * g.K + col));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < g.K) out[row * g.K + col + e] = stg[r * EP_LD + ec + e];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 // Weights fp32 KCRS -> int8 KRSC codes (form SYMMETRIC, FSPTQuant/base.py:149-152: q = clamp(R(w/s_k), lo, hi))
 // plus SUM_k = sum of the codes of output channel k.  One workgroup per output channel.
 __global__ __launch_bounds__(DLMCQ_BLOCK) void quantize_weight_krsc_kernel(const float* __restrict__ w, int8_t* __restrict__ wq,
@@ -623,7 +829,21 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   // many input channels) and there are enough row tiles to fill the chip.  DLMCQ_CONV_VARIANT=2 forces 128 rows.
   const int64_t ksteps = R * S * (C / CV_BK);
   const int bmm = (variant == 3 && bnn == 128 && ksteps >= 8 && M >= 256 * 512) ? 256 : 128;   // measured: no gain
-  (void)ksteps;
+  // the 256-row wave-specialised kernel: only on request (variant 9)
+  const bool ws256 = variant == 9;   // measured: no faster than the 128-row kernel, so not the default
+  if (ws256) {
+    const int bn256 = (K % 256 == 0) ? 256 : ((K % 128 == 0) ? 128 : 64);
+    g.nblk_m = (int)((M + 255) / 256);
+    g.nblk_n = (int)((K + bn256 - 1) / bn256);
+    const int64_t nwg2 = (int64_t)g.nblk_m * g.nblk_n;
+    if (nwg2 >= (1ll << 31)) return DLMCQ_ERANGE;
+#define DLMCQ_CONV_ARGS_256 dim3((uint32_t)nwg2), dim3(768), 0, st, xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift
+    if (bn256 == 256) hipLaunchKernelGGL((conv_i8_ws256_kernel<256>), DLMCQ_CONV_ARGS_256);
+    else if (bn256 == 128) hipLaunchKernelGGL((conv_i8_ws256_kernel<128>), DLMCQ_CONV_ARGS_256);
+    else hipLaunchKernelGGL((conv_i8_ws256_kernel<64>), DLMCQ_CONV_ARGS_256);
+#undef DLMCQ_CONV_ARGS_256
+    return launch_status();
+  }
   g.nblk_m = (int)((M + bmm - 1) / bmm);
   g.nblk_n = (int)((K + bnn - 1) / bnn);
   const int64_t nwg = (int64_t)g.nblk_m * g.nblk_n;
