@@ -31,9 +31,21 @@ constexpr int CV_LD = CV_BK + 16;  // LDS row stride in bytes
 
 struct ConvGeom {
   int N, H, W, C, K, R, S, stride, pad, dil, P, Q;
-  int64_t M;          // N*P*Q
+  int64_t M;          // N*P*Q (< 2^31)
   int nblk_m, nblk_n;
+  FastDiv qdiv, pdiv; // row index -> (n, p, q) without 64-bit divisions
 };
+
+// output row m -> image n and the top-left input coordinate of its receptive field
+__device__ __forceinline__ void row_origin(const ConvGeom& g, uint32_t m, int& n, int& h0, int& w0) {
+  const uint32_t t = fdiv(m, g.qdiv);
+  const int q = (int)(m - t * (uint32_t)g.Q);
+  const uint32_t nn = fdiv(t, g.pdiv);
+  const int p = (int)(t - nn * (uint32_t)g.P);
+  n = (int)nn;
+  h0 = p * g.stride - g.pad;
+  w0 = q * g.stride - g.pad;
+}
 
 template <int BN>
 __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
@@ -71,13 +83,7 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__
   for (int i = 0; i < 2; ++i) {
     const int64_t m = m0 + srow + 64 * i;
     a_ok[i] = m < g.M;
-    const int64_t mm = a_ok[i] ? m : 0;
-    const int q = (int)(mm % g.Q);
-    const int64_t t = mm / g.Q;
-    const int p = (int)(t % g.P);
-    a_n[i] = (int)(t / g.P);
-    a_h0[i] = p * g.stride - g.pad;
-    a_w0[i] = q * g.stride - g.pad;
+    row_origin(g, a_ok[i] ? (uint32_t)m : 0u, a_n[i], a_h0[i], a_w0[i]);
   }
   const int cchunks = g.C / CV_BK;
   const int nsteps = g.R * g.S * cchunks;
@@ -231,13 +237,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
     a_seg[i] = pslot ^ ((row / RPB) & (SLOTS - 1));
     const int64_t m = m0 + row;
     a_ok[i] = m < g.M;
-    const int64_t mm = a_ok[i] ? m : 0;
-    const int q = (int)(mm % g.Q);
-    const int64_t t = mm / g.Q;
-    const int p = (int)(t % g.P);
-    a_n[i] = (int)(t / g.P);
-    a_h0[i] = p * g.stride - g.pad;
-    a_w0[i] = q * g.stride - g.pad;
+    row_origin(g, a_ok[i] ? (uint32_t)m : 0u, a_n[i], a_h0[i], a_w0[i]);
   }
   int b_seg[BI];
   const int8_t* b_src[BI];
@@ -445,13 +445,7 @@ __global__ __launch_bounds__(512) void conv_i8_ws_kernel(const int8_t* __restric
       a_seg[i] = pslot ^ ((row >> 2) & 3);
       const int64_t m = m0 + row;
       a_ok[i] = m < g.M;
-      const int64_t mm = a_ok[i] ? m : 0;
-      const int q = (int)(mm % g.Q);
-      const int64_t t = mm / g.Q;
-      const int p = (int)(t % g.P);
-      a_n[i] = (int)(t / g.P);
-      a_h0[i] = p * g.stride - g.pad;
-      a_w0[i] = q * g.stride - g.pad;
+      row_origin(g, a_ok[i] ? (uint32_t)m : 0u, a_n[i], a_h0[i], a_w0[i]);
     }
     int b_seg[BI];
     const int8_t* b_src[BI];
@@ -598,13 +592,7 @@ __global__ __launch_bounds__(768) void conv_i8_ws256_kernel(const int8_t* __rest
       a_seg[i] = pslot ^ ((row >> 2) & 3);
       const int64_t m = m0 + row;
       a_ok[i] = m < g.M;
-      const int64_t mm = a_ok[i] ? m : 0;
-      const int q = (int)(mm % g.Q);
-      const int64_t t = mm / g.Q;
-      const int p = (int)(t % g.P);
-      a_n[i] = (int)(t / g.P);
-      a_h0[i] = p * g.stride - g.pad;
-      a_w0[i] = q * g.stride - g.pad;
+      row_origin(g, a_ok[i] ? (uint32_t)m : 0u, a_n[i], a_h0[i], a_w0[i]);
     }
     int b_seg[BI];
     const int8_t* b_src[BI];
@@ -821,6 +809,8 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   ConvGeom g;
   g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C = (int)C; g.K = (int)K; g.R = (int)R; g.S = (int)S;
   g.stride = stride; g.pad = pad; g.dil = dilation; g.P = (int)P; g.Q = (int)Q; g.M = M;
+  g.qdiv = make_fastdiv((uint32_t)Q);
+  g.pdiv = make_fastdiv((uint32_t)P);
   const int shift = x_is_unsigned ? 128 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int8_t* xs = reinterpret_cast<const int8_t*>(x);
