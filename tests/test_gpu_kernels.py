@@ -491,3 +491,50 @@ def test_entry_points_are_graph_capturable(K):
         assert_bits_equal(outs["y"].contiguous(), y_ref, f"graph replay scale {scale}")
         eager = torch.nn.functional.conv2d(outs["y"], O.fq_symmetric(w.cpu(), s_w.cpu(), -127, 127)[1].to(DEV), padding=1)
         torch.testing.assert_close(outs["conv"], eager, rtol=1e-4, atol=1e-4)
+
+
+def test_fuzz_shapes_forms_alignments(K):
+    """Seeded fuzz: 150 random (shape, channel axis, form, range, storage offset) combinations, every output
+    (y, fp32 codes, int8 codes, observer) against the oracle bit for bit - ragged sizes, slabs that are not a
+    multiple of 4, single-element channels, misaligned views."""
+    n = N()
+    rng = np.random.default_rng(2333)
+    for case in range(150):
+        rank = int(rng.integers(1, 5))
+        shape = tuple(int(rng.integers(1, 9)) for _ in range(rank - 1)) + (int(rng.integers(1, 70)),)
+        if rank >= 3 and rng.random() < 0.3:
+            shape = shape[:-2] + (7, 7)
+        per_channel = rank >= 2 and rng.random() < 0.6
+        ch_axis = int(rng.integers(0, min(rank, 2))) if per_channel else None
+        signed, bits = RANGES[int(rng.integers(0, len(RANGES)))]
+        lo, hi = O.qrange(signed, bits)
+        form = int(rng.integers(0, 5))
+        g = gen(1000 + case)
+        numel = int(np.prod(shape))
+        off = int(rng.integers(0, 4)) if rng.random() < 0.3 else 0
+        base = torch.randn(numel + off, generator=g)
+        if not signed:
+            base = torch.relu(base) + 0.01
+        x = base[off:].reshape(shape)
+        if ch_axis is None:
+            s = torch.tensor(float(rng.uniform(0.005, 0.05)), dtype=torch.float32)
+            o = torch.tensor(0.0 if signed else (2.0 if form == n.FORM_ZEROPOINT else 0.01), dtype=torch.float32)
+        else:
+            cs = [1] * rank
+            cs[ch_axis] = shape[ch_axis]
+            s = torch.rand(cs, generator=g) * 0.05 + 1e-3
+            o = torch.zeros(cs) if signed else (torch.randint(0, 4, cs, generator=g).float() if form == n.FORM_ZEROPOINT
+                                                else torch.rand(cs, generator=g) * 0.02)
+        gg = 1 / math.sqrt(numel * hi)
+        q_ref, y_ref = _oracle_form(form, x, s, o, lo, hi, gg)
+        xd = base.to(DEV)[off:].reshape(shape)
+        tag = f"fuzz {case}: {shape} ax{ch_axis} form{form} {'s' if signed else 'u'}{bits} off{off}"
+        assert_bits_equal(K.fake_quant(xd, s.to(DEV), o.to(DEV), lo, hi, form, g=gg), y_ref, tag + " y")
+        assert_bits_equal(K.fake_quant(xd, s.to(DEV), o.to(DEV), lo, hi, form, g=gg, y_kind=n.Y_CODES), q_ref, tag + " q")
+        if form != n.FORM_ROOTQ_ACT or lo == 0:
+            _, codes = K.fake_quant(xd, s.to(DEV), o.to(DEV), lo, hi, form, g=gg, codes="i8")
+            assert torch.equal(codes.cpu().to(torch.float32), q_ref), tag + " i8"
+        so, oo = K.observe_qparams(xd, bits, signed, ch_axis=ch_axis)
+        ws, wo = (O.minmax_tensor(x, bits, signed) if ch_axis is None else O.minmax_channel(x, bits, signed, ch_axis=ch_axis))
+        values_equal(so, ws, tag + " scale")
+        values_equal(oo, wo, tag + " offset")
