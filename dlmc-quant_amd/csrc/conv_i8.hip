@@ -48,7 +48,7 @@ __device__ __forceinline__ void row_origin(const ConvGeom& g, uint32_t m, int& n
 }
 
 template <int BN>
-__global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+__global__ __launch_bounds__(256, 2) void conv_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                      float* __restrict__ out, const float* __restrict__ bias,
                                                      const int32_t* __restrict__ wsum, const float* __restrict__ s_in,
                                                      const float* __restrict__ zp_in, const float* __restrict__ s_w,
@@ -89,10 +89,11 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__
   const int nsteps = g.R * g.S * cchunks;
   const int64_t wrow = (int64_t)g.R * g.S * g.C;  // bytes per output channel in KRSC
 
-  // Register staging, one step ahead; (r, s, c-chunk) advance incrementally - no integer division in the loop.
-  i32x4 ra[2], rb[BLOADS];
+  // Register staging, TWO steps ahead (two register sets; the loop is unrolled by two so that their roles are
+  // static); (r, s, c-chunk) advance incrementally - no integer division in the loop.
+  i32x4 ra0[2], ra1[2], rb0[BLOADS], rb1[BLOADS];
   int f_cc = 0, f_s = 0, f_r = 0;   // tap / channel chunk of the NEXT fetch
-  auto fetch = [&]() {
+  auto fetch = [&](i32x4* pa, i32x4* pb) {
     const int c0 = f_cc * CV_BK + seg * 16;
     const int rs = f_r * g.S + f_s;
 #pragma unroll
@@ -101,18 +102,18 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__
       if (a_ok[i] && h >= 0 && h < g.H && ww >= 0 && ww < g.W) {
         const int64_t off = (((int64_t)a_n[i] * g.H + h) * g.W + ww) * g.C + c0;
         const i32x4 v = *reinterpret_cast<const i32x4*>(x + off);
-        ra[i] = i32x4{(int)(v.x ^ xorw), (int)(v.y ^ xorw), (int)(v.z ^ xorw), (int)(v.w ^ xorw)};
+        pa[i] = i32x4{(int)(v.x ^ xorw), (int)(v.y ^ xorw), (int)(v.z ^ xorw), (int)(v.w ^ xorw)};
       } else {
-        ra[i] = i32x4{(int)padw, (int)padw, (int)padw, (int)padw};
+        pa[i] = i32x4{(int)padw, (int)padw, (int)padw, (int)padw};
       }
     }
 #pragma unroll
     for (int i = 0; i < BLOADS; ++i) {
       const int k = n0 + srow + 64 * i;
       if (k < g.K)
-        rb[i] = *reinterpret_cast<const i32x4*>(w + (int64_t)k * wrow + (int64_t)rs * g.C + c0);
+        pb[i] = *reinterpret_cast<const i32x4*>(w + (int64_t)k * wrow + (int64_t)rs * g.C + c0);
       else
-        rb[i] = i32x4{0, 0, 0, 0};
+        pb[i] = i32x4{0, 0, 0, 0};
     }
     if (++f_cc == cchunks) {
       f_cc = 0;
@@ -122,13 +123,13 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__
       }
     }
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, const i32x4* pa, const i32x4* pb) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<i32x4*>(ldsA + (buf * CV_BM + srow + 64 * i) * CV_LD + seg * 16) = ra[i];
+      *reinterpret_cast<i32x4*>(ldsA + (buf * CV_BM + srow + 64 * i) * CV_LD + seg * 16) = pa[i];
 #pragma unroll
     for (int i = 0; i < BLOADS; ++i)
-      *reinterpret_cast<i32x4*>(ldsB + (buf * BN + srow + 64 * i) * CV_LD + seg * 16) = rb[i];
+      *reinterpret_cast<i32x4*>(ldsB + (buf * BN + srow + 64 * i) * CV_LD + seg * 16) = pb[i];
   };
 
   i32x16 acc[NT];
@@ -137,13 +138,8 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0;
 
-  fetch();
-  stage(0);
-  __syncthreads();
   const int arow = wave * 32 + (lane & 31), kq = (lane >> 5) * 16;
-  for (int step = 0; step < nsteps; ++step) {
-    const int buf = step & 1;
-    if (step + 1 < nsteps) fetch();               // global loads in flight under the MFMAs below
+  auto multiply = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < CV_BK / 32; ++ks) {
       const i32x4 af = *reinterpret_cast<const i32x4*>(ldsA + (buf * CV_BM + arow) * CV_LD + ks * 32 + kq);
@@ -153,7 +149,26 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const int8_t* __restrict__
         acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[j], 0, 0, 0);
       }
     }
-    if (step + 1 < nsteps) stage(buf ^ 1);        // the other buffer was last read before the previous barrier
+  };
+
+  fetch(ra0, rb0);                       // step 0
+  if (nsteps > 1) fetch(ra1, rb1);       // step 1
+  stage(0, ra0, rb0);
+  __syncthreads();
+  const int npairs = (nsteps + 1) / 2;
+  for (int pr = 0; pr < npairs; ++pr) {
+    const int step = 2 * pr;
+    // even step: LDS buffer 0 holds `step`, set 1 holds step+1, set 0 is free for step+2
+    if (step + 2 < nsteps) fetch(ra0, rb0);
+    multiply(0);
+    if (step + 1 < nsteps) stage(1, ra1, rb1);
+    __syncthreads();
+    // odd step (skipped as a whole when nsteps is odd and this is the last pair)
+    if (step + 1 < nsteps) {
+      if (step + 3 < nsteps) fetch(ra1, rb1);
+      multiply(1);
+      if (step + 2 < nsteps) stage(0, ra0, rb0);
+    }
     __syncthreads();
   }
 
