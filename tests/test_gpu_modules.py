@@ -468,3 +468,38 @@ def test_integer_checkpoint_roundtrip():
         assert torch.equal(out, ref), (family, wbits, wsigned)
     with pytest.raises(RuntimeError, match="calibrated"):
         export_quantized_state(build("FSPTQ", 8, True, "minmax_channel"))
+
+
+def test_graphed_forward_matches_eager():
+    """The whole quantised forward as one HIP graph (launch-bound small-batch case, BASELINE config 1)."""
+    import time
+    import workloads as W
+    from dlmc.utils.graph import GraphedForward
+    from dlmc.utils.quantize import quantize_model
+    torch.manual_seed(2333)
+    net = W.resnet18().to(DEV).eval()
+    cfg = {"weight": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": True}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": True}},
+           "exclude_layers": [], "override_options": []}
+    quantize_model(net, cfg, None)
+    x = torch.randn(1, 3, 224, 224, device=DEV)
+    with torch.no_grad():
+        net(x)                                   # calibrate eagerly
+        ref = net(x * 0.9)
+    fwd = GraphedForward(net, x)
+    out = fwd(x * 0.9)
+    assert torch.equal(out, ref)
+    with pytest.raises(ValueError):
+        fwd(torch.randn(2, 3, 224, 224, device=DEV))
+    # it is also what makes batch 1 fast: report (not assert) the two latencies
+    def bench(f, n=30):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            f(x)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    with torch.no_grad():
+        eager_ms, graph_ms = bench(net), bench(fwd)
+    print(f"resnet18 b1 W8A8: eager {eager_ms:.2f} ms, graph {graph_ms:.2f} ms")
+    assert graph_ms < eager_ms

@@ -67,6 +67,14 @@ def main():
     quantize_model(m, cfg("minmax_tensor", 8, True, 8, True, False), None)
     x = torch.randn(1, 3, 224, 224, device=DEV)
     dt, fam = time_model(m, x, 20)
+    from dlmc.utils.graph import GraphedForward
+    fwd = GraphedForward(m, x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        fwd(x)
+    torch.cuda.synchronize()
+    graph_ms = (time.perf_counter() - t0) / 50 * 1e3
     from oracle.ref_layers import port_model
     torch.set_num_threads(bench.usable_cores())
     mc = port_model(W.resnet18().eval(), "QBase", a_signed=True)
@@ -79,6 +87,7 @@ def main():
             mc(xc)
             ts.append(time.perf_counter() - t0)
     out["config1_resnet18_b1_w8a8_per_tensor"] = {"gpu_ms": round(dt * 1e3, 3), "gpu_images_per_s": round(1 / dt, 1),
+                                                  "gpu_hipgraph_ms": round(graph_ms, 3),
                                                   "cpu_port_ms": round(statistics.median(ts) * 1e3, 1),
                                                   "cpu_cores": bench.usable_cores(), "kernels": fam}
     # ---- config 3 / 4
