@@ -38,6 +38,8 @@ SIGNATURES = {
     "dlmcq_rootq_weight_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
     "dlmcq_l2norm_scratch_bytes": (_sz, [_i64, _i64, _i64]),
     "dlmcq_l2norm_step_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _p, _sz, _p]),
+    "dlmcq_adaround_weight_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p]),
+    "dlmcq_adaround_weight_bwd_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p]),
     "dlmcq_quantize_weight_krsc_i8": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i32, _p]),
     "dlmcq_conv2d_i8_nhwc_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                                _i32, _i32, _i32, _i32, _p]),

@@ -16,9 +16,36 @@ import torch
 from torch.nn import Module
 
 from .... import _native as N
+from .. import kernels as K
 from .. import ops
 from .._wrapper import InitState, fake_quant, int8_forward, int8_gemm_default, int8_layer_ok, set_scale
 from ..utils import get_qrange
+
+
+class _AdaRoundFn(torch.autograd.Function):
+    """AdaRound weight path: one HIP launch forward, one backward (alpha and the per-channel scale learn;
+    floor() passes no gradient to the weight, exactly as in the reference's op chain)."""
+
+    @staticmethod
+    def forward(ctx, weight, alpha, scale, lo, hi, training):
+        ctx.save_for_backward(weight, alpha, scale)
+        ctx.rng = (lo, hi, training)
+        return K.adaround_weight(weight, alpha, scale, lo, hi, training)
+
+    @staticmethod
+    def backward(ctx, gy):
+        weight, alpha, scale = ctx.saved_tensors
+        lo, hi, training = ctx.rng
+        need_a, need_s = ctx.needs_input_grad[1] and training, ctx.needs_input_grad[2]
+        ga, gs = (None, None)
+        if need_a or need_s:
+            if training:
+                ga, gs = K.adaround_weight_backward(weight, alpha, scale, gy, lo, hi, want_alpha=need_a, want_scale=need_s)
+            else:   # eval form: [alpha >= 0] has no gradient; the scale still multiplies the clamped code
+                y = K.adaround_weight(weight, alpha, scale, lo, hi, False)
+                red = tuple(range(1, y.dim()))
+                gs = (gy * (y / scale)).sum(dim=red, keepdim=True)
+        return None, ga, gs, None, None, None
 
 
 class FSPTQBase(Module):
@@ -141,11 +168,13 @@ class FSPTQBase(Module):
             return self._forward_func(q_input, self.weight)
         recon = self.qconfig["weight"].get("recon_type")
         if recon == "adaround":
-            # block-reconstruction training: alpha is learnable, so this stays a differentiable device
-            # op chain (a fused soft-rounding kernel is a "next" row)
-            q_weight = torch.floor(self.weight / self.wt_scale)
-            q_weight = q_weight + (self.get_soft_targets() if self.training else (self.alpha >= 0).float())
-            weight = q_weight.clamp(self.wt_min_val, self.wt_max_val) * self.wt_scale
+            # block reconstruction: alpha (and the scales) learn - fused soft-rounding kernel, forward and backward
+            if torch.is_grad_enabled() and (self.alpha.requires_grad or self.wt_scale.requires_grad):
+                weight = _AdaRoundFn.apply(self.weight, self.alpha, self.wt_scale, self.wt_min_val, self.wt_max_val,
+                                           bool(self.training))
+            else:
+                weight = K.adaround_weight(self.weight, self.alpha, self.wt_scale, self.wt_min_val, self.wt_max_val,
+                                           self.training)
         elif recon == "dist_recon":
             raise NotImplementedError("recon_type 'dist_recon' is unfinished in the reference "
                                       "(FSPTQuant/base.py:133,143 call undefined code)")

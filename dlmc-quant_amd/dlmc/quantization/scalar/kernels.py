@@ -13,7 +13,7 @@ from ..._native import (CODES_I8, CODES_NONE, CODES_P4, FORM_EMULATE, FORM_QBASE
                         Y_CODES, Y_DEQUANT)
 
 __all__ = ["fake_quant", "dequant_codes", "dequant", "minmax", "observe_qparams", "qparams_from_minmax",
-           "span_scale", "l2norm_step", "quantize_weight_krsc", "conv2d_i8", "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
+           "span_scale", "l2norm_step", "adaround_weight", "adaround_weight_backward", "quantize_weight_krsc", "conv2d_i8", "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
            "PROFILE"]
 
 
@@ -238,6 +238,31 @@ def l2norm_step(x, scale, offset, lo, hi, ch_axis=None):
     N.check(N.lib.dlmcq_l2norm_step_f32(N.ptr(x), N.ptr(sc), N.ptr(off), N.ptr(new), outer, ch, inner, int(lo), int(hi),
                                         N.ptr(scr), scr.numel() * 4, N.stream_ptr()))
     return new.reshape(scale.shape)
+
+
+def adaround_weight(w, alpha, scale, lo, hi, training):
+    """Fused AdaRound weight forward; `scale` is the per-output-channel [K,1,..] scale."""
+    N.require_gpu(w, alpha)
+    w, alpha = w.detach().contiguous(), alpha.detach().contiguous()
+    sc = _f32c(scale.detach(), w).reshape(-1)
+    K_, inner = w.shape[0], w.numel() // max(w.shape[0], 1)
+    y = torch.empty_like(w)
+    N.check(N.lib.dlmcq_adaround_weight_f32(N.ptr(w), N.ptr(alpha), N.ptr(sc), N.ptr(y), K_, inner, int(lo), int(hi),
+                                            int(bool(training)), N.stream_ptr()))
+    return y
+
+
+def adaround_weight_backward(w, alpha, scale, gy, lo, hi, want_alpha=True, want_scale=True):
+    """(g_alpha like w, g_scale shaped like `scale`) of the training-mode AdaRound forward."""
+    N.require_gpu(w, alpha, gy)
+    w, alpha, gy = w.detach().contiguous(), alpha.detach().contiguous(), gy.contiguous()
+    sc = _f32c(scale.detach(), w).reshape(-1)
+    K_, inner = w.shape[0], w.numel() // max(w.shape[0], 1)
+    ga = torch.empty_like(w) if want_alpha else None
+    gs = torch.empty(K_, dtype=torch.float32, device=w.device) if want_scale else None
+    N.check(N.lib.dlmcq_adaround_weight_bwd_f32(N.ptr(w), N.ptr(alpha), N.ptr(sc), N.ptr(gy), N.ptr(ga), N.ptr(gs), K_, inner,
+                                                int(lo), int(hi), N.stream_ptr()))
+    return ga, (None if gs is None else gs.reshape(scale.shape))
 
 
 def quantize_weight_krsc(w, scale, lo, hi):

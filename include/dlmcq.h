@@ -214,6 +214,21 @@ int dlmcq_l2norm_step_f32(const float* x, const float* scale, const float* offse
                           int64_t outer, int64_t channels, int64_t inner, int32_t lo, int32_t hi,
                           void* scratch, size_t scratch_bytes, dlmcq_stream_t stream);
 
+/*
+ * AdaRound weight path of the few-shot PTQ wrapper (FSPTQuant/base.py:69-79,136-141,151-152), per output channel:
+ *   y = clamp(floor(w/s_k) + r, lo, hi) * s_k,  r = clamp(sigmoid(alpha)*1.2 - 0.1, 0, 1) when `training`, else [alpha >= 0]
+ * and its backward w.r.t. alpha and s_k (w receives no gradient through floor):
+ *   g_alpha = gy*s_k*[lo<=q<=hi]*1.2*sig*(1-sig)*[0<=1.2*sig-0.1<=1],   g_scale[k] = sum gy*clamp(q, lo, hi)
+ * w / alpha / y / gy / g_alpha are [out_channels, inner]; g_alpha or g_scale may be NULL.
+ */
+int dlmcq_adaround_weight_f32(const float* w, const float* alpha, const float* scale, float* y,
+                              int64_t out_channels, int64_t inner, int32_t lo, int32_t hi,
+                              int32_t training, dlmcq_stream_t stream);
+int dlmcq_adaround_weight_bwd_f32(const float* w, const float* alpha, const float* scale,
+                                  const float* gy, float* g_alpha, float* g_scale,
+                                  int64_t out_channels, int64_t inner, int32_t lo, int32_t hi,
+                                  dlmcq_stream_t stream);
+
 /* ---- fused int8-dequant x GEMM convolution / linear on the matrix cores ---- */
 
 /*

@@ -503,3 +503,32 @@ def test_graphed_forward_matches_eager():
         eager_ms, graph_ms = bench(net), bench(fwd)
     print(f"resnet18 b1 W8A8: eager {eager_ms:.2f} ms, graph {graph_ms:.2f} ms")
     assert graph_ms < eager_ms
+
+
+def test_adaround_fused_matches_the_reference_chain():
+    """Fused AdaRound forward / backward against the reference's op chain run through autograd on the CPU."""
+    from dlmc.quantization.scalar import kernels as K
+    from oracle import fakequant_oracle as O
+    g = torch.Generator().manual_seed(2333)
+    for shape, (lo, hi) in (((16, 8, 3, 3), (-127, 127)), ((10, 33), (-7, 7)), ((4, 5, 1, 1), (-3, 3))):
+        w = torch.randn(shape, generator=g) * 0.1
+        s, _ = O.minmax_channel(w, 8 if hi == 127 else (4 if hi == 7 else 3), True, ch_axis=0)
+        s = s + 1e-6
+        alpha = torch.randn(shape, generator=g) * 2.0
+        gy = torch.randn(shape, generator=g)
+        # eval form: bit-exact
+        _, y_eval = O.fq_adaround(w, s, alpha, lo, hi, training=False)
+        assert_bits_equal(K.adaround_weight(w.to(DEV), alpha.to(DEV), s.to(DEV), lo, hi, False), y_eval, f"{shape} eval")
+        # training form + gradients (sigmoid differs in the last ulp between CPU and GPU exp)
+        a_ref, s_ref = alpha.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        q = torch.floor(w / s_ref) + torch.clamp(torch.sigmoid(a_ref) * (1.1 - (-0.1)) + (-0.1), 0, 1)
+        y_ref = q.clamp(lo, hi) * s_ref
+        y_ref.backward(gy)
+        y = K.adaround_weight(w.to(DEV), alpha.to(DEV), s.to(DEV), lo, hi, True)
+        close(y, y_ref.detach(), f"{shape} train", rtol=1e-5, atol=1e-6)
+        ga, gs = K.adaround_weight_backward(w.to(DEV), alpha.to(DEV), s.to(DEV), gy.to(DEV), lo, hi)
+        close(ga, a_ref.grad, f"{shape} g_alpha", rtol=1e-4, atol=1e-6)
+        # the reference's scale gradient also receives the (zero-measure) floor(w/s) path: only the product term
+        want_gs = (gy * q.detach().clamp(lo, hi)).sum(dim=tuple(range(1, w.dim())), keepdim=True)
+        close(gs, want_gs, f"{shape} g_scale", rtol=1e-4, atol=1e-5)
+        assert gs.shape == s.shape
