@@ -347,3 +347,22 @@ def repvgg_fuse(k3, bn3, k1, bn1, bnid, groups=1):
         ident[i, i % cg, 1, 1] = 1
     kc, bc = branch(ident, bnid)
     return ka + kb + kc, ba + bb + bc
+
+
+def l2norm_output(layer, x, weight, n_bits, signed, patience=1000):
+    """ops.py:85-109: refine the (per-tensor) weight scale against the layer output."""
+    out = conv_or_linear(layer, x, weight)
+    scale, offset = minmax_tensor(weight, n_bits, signed)
+    lo, hi = qrange(signed, n_bits)
+    diff, best_mse, best_scale, count = float("inf"), float("inf"), scale, 0
+    while diff > 1e-5 and count != patience:
+        wq = quantize_codes(weight, scale, offset, lo, hi)
+        oq = conv_or_linear(layer, x, wq)
+        mse = l2_loss(out, oq)
+        new = (oq * out).mean(axis=0).sum() / (oq * oq + 1e-7).mean(axis=0).sum()
+        diff = float((new - scale).abs() / scale)
+        scale = new
+        if mse < best_mse:
+            best_mse, best_scale = mse, scale
+        count += 1
+    return best_scale, offset

@@ -291,6 +291,22 @@ def case_qbase():
             out=out.detach(), grad_x=xg.grad, grad_weight=q.weight.grad, grad_bias=q.bias.grad,
             grad_in_scale=q.in_scale.grad, grad_wt_scale=q.wt_scale.grad)
         CASES.append(dict(name=name, kind="qbase_grad", layer="conv", qconfig=qcfg))
+    # output-aware weight scale (ops.py:85-109) through QBase (modules/base.py:108-117), as PTQ_output_config.yaml uses it
+    for j, kind in enumerate(("conv", "linear")):
+        g = gen(2700 + j)
+        m, x = make_layer(kind, g)
+        qcfg = {"input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": True}},
+                "weight": {"enable": True, "type": "l2norm_output", "args": {"n_bits": 4, "signed": True}},
+                "momentum": 0.1}
+        cls = modules.QLinear if kind == "linear" else modules.QConv2d
+        q = swap(cls, m, qcfg)
+        cap = Capture(q)
+        with torch.no_grad():
+            out = q(x)
+        name = f"qbase_l2out{j}"
+        put(name, x=x, weight=m.weight, bias=m.bias, in_scale=q.in_scale, wt_scale=q.wt_scale,
+            wt_offset=q.wt_offset.to(torch.float32).reshape(-1), fq_input=cap.input, fq_weight=cap.weight, out=out)
+        CASES.append(dict(name=name, kind="qbase_l2out", layer=kind, qconfig=qcfg))
     # the closed form in FunLSQ.backward (modules/function.py:37-49)
     for j, (lo, hi) in enumerate(((-127, 127), (0, 15))):
         g = gen(2600 + j)

@@ -532,3 +532,31 @@ def test_adaround_fused_matches_the_reference_chain():
         want_gs = (gy * q.detach().clamp(lo, hi)).sum(dim=tuple(range(1, w.dim())), keepdim=True)
         close(gs, want_gs, f"{shape} g_scale", rtol=1e-4, atol=1e-5)
         assert gs.shape == s.shape
+
+
+def test_output_aware_weight_scale_and_function_api(golden):
+    """`l2norm_output` through QBase (ops.py:85-109; PTQ_output_config.yaml) and the explicit autograd Functions."""
+    from dlmc.quantization.scalar.modules import FunLQ, FunLSQ, FunRootQ, FunUniformQ
+    for c in golden.of_kind("qbase_l2out"):
+        net, cap = _quantized(c, golden)
+        with torch.no_grad():
+            out = net(golden.get(c, "x").to(DEV))
+        assert_bits_equal(cap.input, golden.get(c, "fq_input"), c["name"] + ".fq_input")
+        close(net.layer.wt_scale, golden.get(c, "wt_scale"), c["name"] + ".wt_scale", rtol=2e-4, atol=0)
+        close(out, golden.get(c, "out"), c["name"] + ".out", rtol=5e-2, atol=5e-2)   # 4-bit weights: a scale ulp moves codes
+    for c in golden.of_kind("funlsq"):
+        w, s, gout = (golden.get(c, k).to(DEV) for k in ("w", "scale", "gout"))
+        wr, sr = w.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        y = FunLSQ.apply(wr, sr, torch.zeros(1, device=DEV), c["lo"], c["hi"], c["g"])
+        assert_bits_equal(y, golden.get(c, "y"), c["name"] + ".y")
+        y.backward(gout)
+        assert_bits_equal(wr.grad, golden.get(c, "grad_w"), c["name"] + ".grad_w")
+        close(sr.grad, golden.get(c, "grad_scale"), c["name"] + ".grad_scale", rtol=1e-4, atol=1e-6)
+        for fn, nargs in ((FunUniformQ, 5), (FunRootQ, 5), (FunLQ, 6)):
+            wr = w.clone().requires_grad_(True)
+            args = (wr, s, torch.zeros(1, device=DEV), c["lo"], c["hi"]) + ((c["g"],) if nargs == 6 else ())
+            y = fn.apply(*args)
+            y.sum().backward()
+            assert wr.grad is not None and wr.grad.shape == w.shape
+            if fn is not FunLQ:
+                assert_bits_equal(y, golden.get(c, "y"), fn.__name__)

@@ -259,3 +259,14 @@ def test_weight_transforms(golden):
                              bn("rbr_identity") if c["has_identity"] else None, groups=c["groups"])
         assert_bits_equal(k, golden.get(c, "out_kernel"), c["name"] + ".kernel")
         assert_bits_equal(b, golden.get(c, "out_bias"), c["name"] + ".bias")
+
+
+def test_output_aware_estimator(golden):
+    for c in golden.of_kind("qbase_l2out"):
+        m = _layer(c, golden)
+        x = golden.get(c, "x")
+        s_in, o_in = O.minmax_tensor(x, 8, True)
+        _, xq = O.fq_qbase(x, s_in.reshape(1), o_in, -127, 127, 1 / math.sqrt(x.numel() * 127))
+        assert_bits_equal(xq, golden.get(c, "fq_input"))
+        s, o = O.l2norm_output(m, xq, m.weight.detach(), 4, True)
+        torch.testing.assert_close(s.reshape(1), golden.get(c, "wt_scale"), rtol=1e-4, atol=0)
