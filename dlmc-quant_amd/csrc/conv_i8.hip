@@ -197,6 +197,40 @@ __global__ __launch_bounds__(256, 2) void conv_i8_kernel(const int8_t* __restric
 //     16-byte segment p ^ ((r >> 2) & 3), and the fragment reads apply the same involution;
 //   * DMA cannot transform or synthesise bytes: the uint8 -> int8 shift (q ^ 0x80) is applied to the A fragment
 //     after the ds_read, and padded taps / rows beyond K read a 16-byte line of a constant table instead.
+// What the LDS-DMA kernel does with a finished output element besides storing it (all optional): add a residual
+// tensor of the output's shape, apply ReLU, and emit the NEXT layer's activation codes - the consumer's own
+// fake-quant (its scale / zero point / range / form) evaluated on the value still in a register, so the fp32
+// tensor, the ReLU pass and the consumer's quantise pass never touch HBM.  Same arithmetic, same order, as the
+// separate kernels (fq_one), hence bit-identical codes.
+struct ConvEpi {
+  const float* residual;
+  uint8_t* codes;
+  const float* q_scale;
+  const float* q_zp;
+  float q_lo, q_hi, q_g;
+  int q_form;
+  int relu;
+};
+
+struct EpiQuant {   // the consumer's constants, resolved once per thread
+  float dv, of, lo, hi;
+  int form;
+  __device__ __forceinline__ EpiQuant(const ConvEpi& ep) : dv(1.0f), of(0.0f), lo(ep.q_lo), hi(ep.q_hi), form(ep.q_form) {
+    if (!ep.codes) return;
+    const float s = ep.q_scale[0];
+    of = ep.q_zp ? ep.q_zp[0] : 0.0f;
+    dv = form == DLMCQ_FORM_EMULATE ? s + 1e-7f : (form == DLMCQ_FORM_QBASE ? ste_scale(s, ep.q_g) : s);
+  }
+  __device__ __forceinline__ uint32_t code(float v) const {
+    float q;
+    if (form == DLMCQ_FORM_EMULATE) q = clamp_nan(__builtin_rintf((v - of) / dv), lo, hi);
+    else if (form == DLMCQ_FORM_QBASE) q = ste_round(clamp_nan((v - of) / dv, lo, hi));
+    else if (form == DLMCQ_FORM_ZEROPOINT) q = clamp_nan(ste_round(v / dv) + of, lo, hi);
+    else q = clamp_nan(ste_round(v / dv), lo, hi);
+    return (uint32_t)(code_of(q) & 0xff);
+  }
+};
+
 struct PadTable {
   int8_t b[256 * 16];
   constexpr PadTable() : b() {
@@ -216,7 +250,8 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
                                                          const int32_t* __restrict__ wsum,
                                                          const float* __restrict__ s_in,
                                                          const float* __restrict__ zp_in,
-                                                         const float* __restrict__ s_w, ConvGeom g, int shift) {
+                                                         const float* __restrict__ s_w, ConvGeom g, int shift,
+                                                         ConvEpi ep) {
   constexpr int PF = NBUF - 1;  // K steps in flight
   constexpr int TILE_A = BM * BK, TILE_B = BN * BK, TILE = TILE_A + TILE_B;
   constexpr int MT = BM / 128;  // 32-row slabs per wave along M (a wave owns BM/4 consecutive rows)
@@ -359,6 +394,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
   }
 
   const float sin = s_in[0];
+  const EpiQuant eq(ep);
   constexpr bool EP_FITS = 4 * 32 * 68 * 4 <= NBUF * TILE;   // the LDS epilogue stage re-uses the operand buffers
   if (MT == 1 && EP_FITS && (g.K & 3) == 0) {
     // ---- epilogue through LDS: accumulator layout (lane = channel, register = row) -> row-major, so that each
@@ -392,8 +428,19 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
       for (int it = 0; it < 8; ++it) {
         const int r = it * 4 + er;
         const int64_t row = m0 + wrow0 + r;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * EP_LD + ec);
-        if (row < g.M && col < g.K) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + row * g.K + col));
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * EP_LD + ec);
+        if (row < g.M && col < g.K) {
+          const int64_t at = row * g.K + col;
+          if (ep.residual) {
+            const f32x4 idt = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ep.residual + at));
+            v = f32x4{v.x + idt.x, v.y + idt.y, v.z + idt.z, v.w + idt.w};
+          }
+          if (ep.relu) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
+          if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
+          if (ep.codes)
+            __builtin_nontemporal_store(eq.code(v.x) | (eq.code(v.y) << 8) | (eq.code(v.z) << 16) | (eq.code(v.w) << 24),
+                                        reinterpret_cast<uint32_t*>(ep.codes + at));
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the stage
     }
@@ -411,7 +458,13 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int64_t row = m0 + wrow0 + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        if (row < g.M) __builtin_nontemporal_store((float)(acc[mi][j][i] + corr) * mult + bv, out + row * g.K + col);
+        if (row >= g.M) continue;
+        const int64_t at = row * g.K + col;
+        float v = (float)(acc[mi][j][i] + corr) * mult + bv;
+        if (ep.residual) v = v + ep.residual[at];
+        if (ep.relu) v = relu_nan(v);
+        if (out) __builtin_nontemporal_store(v, out + at);
+        if (ep.codes) ep.codes[at] = (uint8_t)eq.code(v);
       }
   }
 }
@@ -809,7 +862,10 @@ static int conv_variant() {
 static int conv_launch(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
                        const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N, int64_t H,
                        int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
-                       int32_t dilation, int32_t x_is_unsigned, dlmcq_stream_t stream, int variant) {
+                       int32_t dilation, int32_t x_is_unsigned, dlmcq_stream_t stream, int variant,
+                       const ConvEpi& ep = ConvEpi{}) {
+  const bool fused = ep.residual || ep.codes || ep.relu;
+  if (fused && !(variant == 1 || variant == 2 || variant == 3)) return DLMCQ_EINVAL;   // only the LDS-DMA kernel fuses
   if (N < 0 || H < 1 || W < 1 || C < 1 || K < 1 || R < 1 || S < 1 || stride < 1 || pad < 0 || dilation < 1)
     return DLMCQ_EINVAL;
   if (C % CV_BK != 0) return DLMCQ_EINVAL;  // the K step is 64 input channels
@@ -818,8 +874,13 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   if (P < 1 || Q < 1) return DLMCQ_EINVAL;
   const int64_t M = N * P * Q;
   if (M == 0) return DLMCQ_OK;
-  if (!x || !w || !out || !wsum || !in_scale || !w_scale) return DLMCQ_EINVAL;
-  if (!aligned16(x) || !aligned16(w)) return DLMCQ_EALIGN;
+  if (!x || !w || !(out || ep.codes) || !wsum || !in_scale || !w_scale) return DLMCQ_EINVAL;
+  if (ep.codes && (!ep.q_scale || ep.q_lo > ep.q_hi || ep.q_lo < -128.0f || ep.q_hi > 255.0f || ep.q_hi - ep.q_lo > 255.0f ||
+                   ep.q_form < DLMCQ_FORM_EMULATE || ep.q_form > DLMCQ_FORM_SYMMETRIC))
+    return DLMCQ_EINVAL;
+  if (!aligned16(x) || !aligned16(w) || (out && !aligned16(out)) || (ep.residual && !aligned16(ep.residual)) ||
+      (ep.codes && !aligned4(ep.codes)))
+    return DLMCQ_EALIGN;
   if (M >= (1ll << 31) || N * H * W * C >= (1ll << 40) || K >= (1 << 24)) return DLMCQ_ERANGE;
   ConvGeom g;
   g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C = (int)C; g.K = (int)K; g.R = (int)R; g.S = (int)S;
@@ -861,22 +922,12 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   } else if (variant == 0) {
     if (bnn == 64) hipLaunchKernelGGL((conv_i8_kernel<64>), DLMCQ_CONV_ARGS);
     else hipLaunchKernelGGL((conv_i8_kernel<128>), DLMCQ_CONV_ARGS);
-  } else if (variant >= 10 && variant <= 17 && bnn == 128) {   // timing-only ablations (wrong results by design)
-    switch (variant - 10) {
-      case 1: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 1>), DLMCQ_CONV_ARGS); break;
-      case 2: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 2>), DLMCQ_CONV_ARGS); break;
-      case 4: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 4>), DLMCQ_CONV_ARGS); break;
-      case 6: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 6>), DLMCQ_CONV_ARGS); break;
-      case 5: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 5>), DLMCQ_CONV_ARGS); break;
-      case 3: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 3>), DLMCQ_CONV_ARGS); break;
-      default: hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 7>), DLMCQ_CONV_ARGS); break;
-    }
   } else if (bmm == 256) {
-    hipLaunchKernelGGL((conv_i8_dma_kernel<256, 128>), DLMCQ_CONV_ARGS);
+    hipLaunchKernelGGL((conv_i8_dma_kernel<256, 128>), DLMCQ_CONV_ARGS, ep);
   } else if (bnn == 64) {
-    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 64>), DLMCQ_CONV_ARGS);
+    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 64>), DLMCQ_CONV_ARGS, ep);
   } else {
-    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128>), DLMCQ_CONV_ARGS);
+    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128>), DLMCQ_CONV_ARGS, ep);
   }
 #undef DLMCQ_CONV_ARGS
 #undef DLMCQ_CONV_ARGS_WS
@@ -892,9 +943,31 @@ extern "C" int dlmcq_conv2d_i8_nhwc_f32(const void* x, const int8_t* w, float* o
                      x_is_unsigned, stream, conv_variant());
 }
 
+extern "C" int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float* out, const float* bias,
+                                          const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                                          const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
+                                          int64_t R, int64_t S, int32_t stride, int32_t pad, int32_t dilation,
+                                          int32_t x_is_unsigned, const float* residual, int32_t relu, void* codes,
+                                          const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
+                                          int32_t q_form, float q_ste_g, dlmcq_stream_t stream) {
+  ConvEpi ep{};
+  ep.residual = residual;
+  ep.relu = relu != 0;
+  ep.codes = static_cast<uint8_t*>(codes);
+  ep.q_scale = q_scale;
+  ep.q_zp = q_zero_point;
+  ep.q_lo = (float)q_lo;
+  ep.q_hi = (float)q_hi;
+  ep.q_g = q_ste_g;
+  ep.q_form = q_form;
+  const int v = conv_variant();
+  return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
+                     x_is_unsigned, stream, (v >= 1 && v <= 3) ? v : 1, ep);
+}
+
 // NOT part of the ABI (absent from include/dlmcq.h): the same call with an explicit kernel variant, for the tests and
 // for A/B measurements in one process.  0 register-staged, 1 LDS-DMA (default), 3 LDS-DMA with 256-row tiles where
-// eligible, 4 wave-specialised loader/consumer.  (Deeper rings - 4 / 5 LDS buffers - and 128-byte K steps were also
+// eligible, 4 wave-specialised loader/consumer, 9 wave-specialised 256-row tiles.  (Deeper rings - 4 / 5 LDS buffers - and 128-byte K steps were also
 // measured through the NBUF / BK template parameters and lost 5-40 %: occupancy matters more here)
 extern "C" int dlmcq_x_conv2d_i8_variant(const void* x, const int8_t* w, float* out, const float* bias,
                                          const int32_t* wsum, const float* in_scale, const float* in_zero_point,

@@ -19,55 +19,6 @@
 
 namespace dlmcq {
 
-// Per-channel constants of one form, derived from the stored (scale, offset) exactly as the
-// reference derives them, once per float4 (or once per thread when the whole tensor shares them).
-template <int FORM>
-struct ChanConst {
-  float dv;   // divisor
-  float ml;   // multiplier of the dequant
-  float of;   // offset / zero point
-  float up;   // ROOTQ_ACT: upper clip
-  __device__ __forceinline__ ChanConst(float s, float o, float g, float lo, float hi) {
-    of = o;
-    up = 0.0f;
-    if (FORM == DLMCQ_FORM_EMULATE) {
-      dv = s + 1e-7f;
-      ml = s;
-    } else if (FORM == DLMCQ_FORM_QBASE) {
-      dv = ste_scale(s, g);
-      ml = dv;
-    } else {
-      dv = s;
-      ml = s;
-      if (FORM == DLMCQ_FORM_ROOTQ_ACT) up = s * (hi - lo);
-    }
-  }
-};
-
-// One element: returns the code q (fp32, integral or NaN) and the fake-quantised value y.
-template <int FORM>
-__device__ __forceinline__ void fq_one(float x, const ChanConst<FORM>& c, float lo, float hi, float& q,
-                                       float& y) {
-  if (FORM == DLMCQ_FORM_EMULATE) {
-    q = clamp_nan(__builtin_rintf((x - c.of) / c.dv), lo, hi);
-    y = q * c.ml + c.of;
-  } else if (FORM == DLMCQ_FORM_QBASE) {
-    q = ste_round(clamp_nan((x - c.of) / c.dv, lo, hi));
-    y = q * c.ml + c.of;
-  } else if (FORM == DLMCQ_FORM_ZEROPOINT) {
-    q = clamp_nan(ste_round(x / c.dv) + c.of, lo, hi);
-    y = (q - c.of) * c.ml;
-  } else if (FORM == DLMCQ_FORM_SYMMETRIC) {
-    q = clamp_nan(ste_round(x / c.dv), lo, hi);
-    y = q * c.ml;
-  } else {  // DLMCQ_FORM_ROOTQ_ACT
-    float t = x + relu_nan(0.0f - x);
-    t = t - relu_nan(t - c.up);
-    q = ste_round(t / c.dv);
-    y = q * c.ml;
-  }
-}
-
 // Four elements sharing one channel.
 template <int FORM>
 __device__ __forceinline__ void fq4(const f32x4& v, const ChanConst<FORM>& c, float lo, float hi, f32x4& q, f32x4& y) {

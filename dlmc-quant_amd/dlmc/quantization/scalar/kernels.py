@@ -282,10 +282,26 @@ def quantize_weight_krsc(w, scale, lo, hi):
     return wq, wsum
 
 
-def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1, variant=None):
+class EmitCodes:
+    """The consumer's activation quantiser, for a producer that emits its codes directly (conv2d_i8 `emit=`)."""
+
+    def __init__(self, scale, zero_point, lo, hi, form, g=0.0):
+        self.scale, self.zero_point, self.lo, self.hi, self.form, self.g = scale, zero_point, int(lo), int(hi), int(form), float(g)
+
+    @property
+    def dtype(self):
+        return torch.uint8 if self.lo >= 0 else torch.int8
+
+
+def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1, variant=None,
+              residual=None, relu=False, emit=None, want_out=True):
     """Fused int8 conv / linear on the matrix cores.  `codes`: uint8/int8 activation codes, logically
     (N, C, H, W) in channels_last memory, or (N, C) for a linear layer.  Returns fp32 (N, K, P, Q) in
-    channels_last memory (or (N, K))."""
+    channels_last memory (or (N, K)).
+
+    Epilogue options (dlmcq_conv2d_i8_nhwc_fused): `residual` (fp32, the output's shape and layout) is added,
+    `relu` applied, and with `emit=EmitCodes(...)` the consumer's activation codes of the result are written as
+    well; the return value is then `(out, out_codes)`, `out` being None when `want_out=False`."""
     N.require_gpu(codes, wq)
     linear = codes.dim() == 2
     if linear:
@@ -299,21 +315,52 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
     K, R, S, _ = wq.shape
     P = (h + 2 * padding - dilation * (R - 1) - 1) // stride + 1
     Q = (w_ + 2 * padding - dilation * (S - 1) - 1) // stride + 1
-    if linear:
-        out = torch.empty((n, K), dtype=torch.float32, device=codes.device)
-    else:
-        out = torch.empty((n, K, P, Q), dtype=torch.float32, device=codes.device, memory_format=torch.channels_last)
-    w_scale = _f32c(w_scale.detach(), out).reshape(-1)
+
+    def alloc(dtype):
+        if linear:
+            return torch.empty((n, K), dtype=dtype, device=codes.device)
+        return torch.empty((n, K, P, Q), dtype=dtype, device=codes.device, memory_format=torch.channels_last)
+    fused = residual is not None or relu or emit is not None
+    if not want_out and emit is None:
+        raise ValueError("conv2d_i8: nothing to produce (want_out=False without emit)")
+    out = alloc(torch.float32) if want_out else None
+    ref = codes   # device / dtype anchor for the small parameter tensors
+    w_scale = _f32c(w_scale.detach(), ref).reshape(-1)
     if w_scale.numel() == 1:
         w_scale = w_scale.expand(K).contiguous()
-    in_scale = _f32c(in_scale.detach(), out).reshape(-1)
-    in_zp = None if in_zp is None else _f32c(in_zp, out).reshape(-1)
+    in_scale = _f32c(in_scale.detach(), ref).reshape(-1)
+    in_zp = None if in_zp is None else _f32c(in_zp, ref).reshape(-1)
     bias = None if bias is None else bias.detach().contiguous()
-    macs = n * P * Q * K * R * S * c
     args = (N.ptr(codes), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),
-            n, h, w_, c, K, R, S, int(stride), int(padding), int(dilation), int(codes.dtype == torch.uint8), N.stream_ptr())
+            n, h, w_, c, K, R, S, int(stride), int(padding), int(dilation), int(codes.dtype == torch.uint8))
+    out_elems = n * K * P * Q
+    if fused:
+        if variant is not None:
+            raise ValueError("conv2d_i8: the epilogue options exist only in the default kernel")
+        out_codes = q_scale = q_zp = None
+        lo = hi = form = 0
+        g = 0.0
+        if residual is not None:
+            if tuple(residual.shape) != ((n, K) if linear else (n, K, P, Q)) or residual.dtype != torch.float32:
+                raise ValueError("conv2d_i8: residual must be fp32 of the output's shape")
+            N.require_gpu(residual)
+            if linear:
+                residual = residual.contiguous()
+            elif not residual.is_contiguous(memory_format=torch.channels_last):
+                residual = residual.contiguous(memory_format=torch.channels_last)
+        if emit is not None:
+            out_codes = alloc(emit.dtype)
+            q_scale = _f32c(emit.scale.detach(), ref).reshape(-1)
+            q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, ref).reshape(-1)
+            lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
+        nbytes = codes.numel() + wq.numel() + out_elems * (4 * (out is not None) + 4 * (residual is not None) + (emit is not None))
+        PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_fused(
+            *args, N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g,
+            N.stream_ptr())))
+        return (out, out_codes) if emit is not None else out
+    args = args + (N.stream_ptr(),)
     if variant is None:
-        PROFILE.launch("conv_i8", codes.numel() + out.numel() * 4 + wq.numel(),
+        PROFILE.launch("conv_i8", codes.numel() + out_elems * 4 + wq.numel(),
                        lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(*args)))
     else:   # test / tuning hook outside the ABI
         N.check(N.experimental("dlmcq_x_conv2d_i8_variant", N.SIGNATURES["dlmcq_conv2d_i8_nhwc_f32"][1] + [N._i32])(*args, int(variant)))

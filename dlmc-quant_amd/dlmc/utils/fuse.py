@@ -1,0 +1,292 @@
+"""Frozen-network execution plan: fold what FOLLOWS each quantised layer into that layer's int8 kernel.
+
+In the reference every wrapper is an island (`modules/conv.py:13-19`, `FSPTQuant/base.py:95-159`): it reads an
+fp32 activation, fake-quantises it, convolves, and writes an fp32 activation which a ReLU module re-reads and
+re-writes, a residual add re-reads and re-writes, and the next wrapper re-reads to quantise again.  Once the
+scales are frozen (after calibration / PTQ - the state `post_training_quantization.py:77` evaluates in) none of
+those trips through HBM is needed: the value that leaves the matrix-core accumulator can be dequantised, added to
+the shortcut, rectified and turned into the NEXT layer's activation code while it is still in a register
+(`dlmcq_conv2d_i8_nhwc_fused`).  Arithmetic and order are those of the separate kernels, so the codes - and hence
+every downstream value - are bit-identical to the unfused wrappers; only the memory traffic changes.
+
+    model = ...; quantize_model(model, cfg, logger, "FSPTQ"); model(calib_batch)      # calibrated, on the GPU
+    fused = fuse_inference(model)            # torch.fx GraphModule over the same parameters
+    y = fused(x)                             # == model(x) bit for bit (up to the sign of zero)
+
+`torch.fx` is used once, as a dataflow reader (which ReLU / add / wrapper consumes which tensor); execution is the
+explicit HIP launches of the plan, and the result can be captured with `dlmc.utils.graph.GraphedForward`.
+The plan snapshots weights and scales: re-fuse after changing them.
+"""
+import math
+import operator
+
+import torch
+import torch.fx as fx
+import torch.nn.functional as F
+from torch import nn
+
+from .. import _native as N
+from ..quantization.scalar import kernels as K
+from ..quantization.scalar._wrapper import int8_layer_ok, ste_scale_value
+from ..quantization.scalar.FSPTQuant.base import FSPTQBase
+from ..quantization.scalar.modules.base import QBase
+from ..quantization.scalar.RootQ.base import RootQBase
+
+__all__ = ["fuse_inference", "Int8Layer", "FusionReport"]
+
+
+# ---------------------------------------------------------------------------------- frozen quantiser specs
+class _ActSpec:
+    """One wrapper's frozen activation quantiser, as a producer has to evaluate it."""
+
+    def __init__(self, scale, zp, lo, hi, form, needs_g):
+        self.scale, self.zp, self.lo, self.hi, self.form, self.needs_g = scale, zp, int(lo), int(hi), form, needs_g
+        self.key = (form, self.lo, self.hi, float(scale.reshape(-1)[0]), 0.0 if zp is None else float(zp.reshape(-1)[0]),
+                    needs_g)
+
+    def g(self, numel):
+        return 1 / math.sqrt(numel * self.hi) if self.needs_g else 0.0
+
+    def emit(self, numel):
+        return K.EmitCodes(self.scale, self.zp, self.lo, self.hi, self.form, self.g(numel))
+
+
+def _byte_range(lo, hi):
+    return (0 <= lo and hi <= 255) or (-128 <= lo and hi <= 127)
+
+
+def _frozen_spec(mod):
+    """(_ActSpec, weight scale, weight lo, weight hi) if `mod` can run on the int8 kernel with frozen scales."""
+    if isinstance(mod, FSPTQBase):
+        if not (mod.act_quant and mod.wt_quant) or mod.in_scale.numel() != 1 or not int8_layer_ok(mod):
+            return None
+        if mod.qconfig["weight"].get("recon_type") in ("adaround", "dist_recon"):
+            return None
+        if not (mod._init.ready(mod, "in_init_state") and mod._init.ready(mod, "wt_init_state")):
+            raise RuntimeError("fuse_inference: run a calibration forward first (scales are not initialised)")
+        if not (_byte_range(mod.in_min_val, mod.in_max_val) and -128 <= mod.wt_min_val and mod.wt_max_val <= 127):
+            return None
+        zp = mod.in_offset.detach().to(torch.float32).reshape(-1)[:1].clone()
+        z = float(zp[0])
+        if z != round(z) or not (mod.in_min_val <= z <= mod.in_max_val):
+            return None
+        act = _ActSpec(mod.in_scale.detach().reshape(-1)[:1].clone(), zp, mod.in_min_val, mod.in_max_val,
+                       N.FORM_ZEROPOINT, False)
+        return act, mod.wt_scale.detach().clone(), mod.wt_min_val, mod.wt_max_val
+    if isinstance(mod, QBase):
+        cfg = mod.qconfig
+        if not (cfg["input"]["enable"] and cfg["weight"]["enable"]) or not int8_layer_ok(mod):
+            return None
+        if mod.in_scale.numel() != 1 or mod.wt_scale.numel() != 1:
+            return None
+        if not (mod._init.ready(mod, "in_init_state") and mod._init.ready(mod, "wt_init_state")):
+            raise RuntimeError("fuse_inference: run a calibration forward first (scales are not initialised)")
+        if not (_byte_range(mod.in_min_val, mod.in_max_val) and -128 <= mod.wt_min_val and mod.wt_max_val <= 127):
+            return None
+        if float(mod.in_offset.abs().max()) != 0 or float(mod.wt_offset.abs().max()) != 0:
+            return None
+        act = _ActSpec(mod.in_scale.detach().reshape(-1)[:1].clone(), None, mod.in_min_val, mod.in_max_val,
+                       N.FORM_QBASE, True)
+        g_w = 1 / math.sqrt(mod.weight.numel() * mod.wt_max_val)
+        return act, ste_scale_value(mod.wt_scale, g_w).clone(), mod.wt_min_val, mod.wt_max_val
+    return None
+
+
+# -------------------------------------------------------------------------------------------- plan nodes
+class Int8Layer(nn.Module):
+    """One quantised conv / linear of the frozen plan.  Input: the producer's codes (uint8/int8) or an fp32
+    tensor (quantised here, one pass).  Output: `(fp32 or None, consumer codes or None)`."""
+
+    def __init__(self, layer, spec, relu=False, emit=None, want_out=True):
+        super().__init__()
+        self.layer = layer
+        self.act, w_scale, w_lo, w_hi = spec
+        self.relu, self.emit, self.want_out = bool(relu), emit, bool(want_out)
+        wq, wsum = K.quantize_weight_krsc(layer.weight, w_scale, w_lo, w_hi)
+        k = layer.weight.shape[0]
+        w_scale = w_scale.detach().to(torch.float32).reshape(-1)
+        self.register_buffer("wq", wq, persistent=False)
+        self.register_buffer("wsum", wsum, persistent=False)
+        self.register_buffer("w_scale", (w_scale.expand(k) if w_scale.numel() == 1 else w_scale).contiguous(),
+                             persistent=False)
+        self._deq = {}     # QBase dequantises with s^ = grad_scale(s, g(numel)): one tiny tensor per input size
+
+    def _in_scale(self, numel):
+        if not self.act.needs_g:
+            return self.act.scale
+        s = self._deq.get(numel)
+        if s is None:
+            s = self._deq[numel] = ste_scale_value(self.act.scale, self.act.g(numel)).contiguous()
+        return s
+
+    def forward(self, x, residual=None):
+        lay, act = self.layer, self.act
+        linear = lay.weight.dim() == 2
+        lead = None
+        if linear and x.dim() != 2:
+            lead = x.shape[:-1]
+            x = x.reshape(-1, x.shape[-1])
+            if residual is not None:
+                residual = residual.reshape(-1, residual.shape[-1])
+        numel = x.numel()
+        if x.dtype in (torch.uint8, torch.int8):
+            codes = x
+        else:
+            N.require_gpu(x)
+            if x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
+                x = x.contiguous(memory_format=torch.channels_last)
+            _, codes = K.fake_quant(x, act.scale, act.zp, act.lo, act.hi, act.form, g=act.g(numel), codes="i8", want_y=False)
+        kw = {} if linear else dict(stride=lay.stride[0], padding=lay.padding[0], dilation=lay.dilation[0])
+        if self.relu or residual is not None or self.emit is not None:
+            emit = None
+            if self.emit is not None:
+                k = lay.weight.shape[0]
+                out_numel = None
+                if self.emit.needs_g:      # the consumer's g uses ITS input size = this layer's output size
+                    if linear:
+                        out_numel = codes.shape[0] * k
+                    else:
+                        r, s = lay.weight.shape[2], lay.weight.shape[3]
+                        p = (codes.shape[2] + 2 * lay.padding[0] - lay.dilation[0] * (r - 1) - 1) // lay.stride[0] + 1
+                        q = (codes.shape[3] + 2 * lay.padding[0] - lay.dilation[0] * (s - 1) - 1) // lay.stride[0] + 1
+                        out_numel = codes.shape[0] * k * p * q
+                emit = self.emit.emit(out_numel)
+            res = K.conv2d_i8(codes, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale,
+                              residual=residual, relu=self.relu, emit=emit, want_out=self.want_out, **kw)
+            out, out_codes = res if emit is not None else (res, None)
+        else:
+            out, out_codes = K.conv2d_i8(codes, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale, **kw), None
+        if lead is not None:
+            out = None if out is None else out.reshape(*lead, out.shape[-1])
+            out_codes = None if out_codes is None else out_codes.reshape(*lead, out_codes.shape[-1])
+        return out, out_codes
+
+
+class FusionReport:
+    """What the pass did, for logs and tests."""
+
+    def __init__(self):
+        self.layers = self.relu = self.residual = self.emit = self.fp32_outputs = 0
+        self.skipped = []
+
+    def __repr__(self):
+        return (f"FusionReport(int8 layers={self.layers}, relu fused={self.relu}, residual fused={self.residual}, "
+                f"code-emitting={self.emit}, fp32 outputs kept={self.fp32_outputs}, not eligible={self.skipped})")
+
+
+class _Tracer(fx.Tracer):
+    def is_leaf_module(self, m, qualname):
+        return isinstance(m, (QBase, FSPTQBase, RootQBase)) or super().is_leaf_module(m, qualname)
+
+
+_ADD_FNS = (operator.add, operator.iadd, torch.add)
+_RELU_FNS = (F.relu, torch.relu, torch.relu_, F.relu_)
+
+
+def _is_add(node):
+    if node.kwargs:
+        return False
+    if node.op == "call_function" and node.target in _ADD_FNS:
+        return len(node.args) == 2 and all(isinstance(a, fx.Node) for a in node.args)
+    if node.op == "call_method" and node.target in ("add", "add_"):
+        return len(node.args) == 2 and all(isinstance(a, fx.Node) for a in node.args)
+    return False
+
+
+def _is_relu(node, modules):
+    if node.op == "call_module":
+        return type(modules.get(node.target)) is nn.ReLU
+    if node.op == "call_function":
+        return node.target in _RELU_FNS
+    return node.op == "call_method" and node.target in ("relu", "relu_")
+
+
+def fuse_inference(model, report=None):
+    """Return a `torch.fx.GraphModule` executing `model`'s calibrated quantised forward as the fused int8 plan.
+    Layers that are not eligible (grouped / 3-channel convs, non-integer zero points, RootQ, ...) keep running
+    their own wrapper.  `model` must be on the GPU, in eval mode, already calibrated."""
+    if model.training:
+        raise RuntimeError("fuse_inference: the plan is for inference - call model.eval() first")
+    report = report if report is not None else FusionReport()
+    graph = _Tracer().trace(model)
+    gm = fx.GraphModule(model, graph)
+    modules = dict(gm.named_modules())
+    specs = {}
+
+    def spec_of(node):
+        if node.op != "call_module" or len(node.args) != 1 or node.kwargs:
+            return None
+        if node.target not in specs:
+            mod = modules[node.target]
+            specs[node.target] = _frozen_spec(mod) if isinstance(mod, (QBase, FSPTQBase)) else None
+            if specs[node.target] is None and isinstance(mod, (QBase, FSPTQBase, RootQBase)):
+                report.skipped.append(node.target)
+        return specs[node.target]
+
+    # folded BatchNorms (merge_bn leaves nn.Identity) and eval-mode Dropout are wires, not operations
+    for node in list(graph.nodes):
+        if node.op == "call_module" and isinstance(modules[node.target], (nn.Identity, nn.Dropout)) and len(node.args) == 1:
+            node.replace_all_uses_with(node.args[0])
+            graph.erase_node(node)
+
+    count = 0
+    for node in list(graph.nodes):
+        spec = spec_of(node)
+        if spec is None:
+            continue
+        # ---- the chain  layer -> (+ shortcut) -> ReLU, each link the sole user of the previous one ----
+        chain, last, residual, relu = [node], node, None, False
+        users = list(last.users)
+        if len(users) == 1 and _is_add(users[0]) and users[0].args[0] is not users[0].args[1]:
+            add = users[0]
+            residual = add.args[1] if add.args[0] is last else add.args[0]
+            chain.append(add)
+            last = add
+            users = list(last.users)
+        if len(users) == 1 and _is_relu(users[0], modules):
+            relu = True
+            chain.append(users[0])
+            last = users[0]
+        # ---- who reads the result: int8 layers fed ONLY through their activation argument take codes ----
+        consumers = {}
+        fp32_needed = False
+        for u in last.users:
+            s = spec_of(u) if u.args and u.args[0] is last else None
+            if s is None:
+                fp32_needed = True
+            else:
+                consumers.setdefault(s[0].key, []).append((u, s[0]))
+        emit, takers = None, []
+        if consumers:
+            key = max(consumers, key=lambda k: len(consumers[k]))
+            takers = [u for u, _ in consumers[key]]
+            emit = consumers[key][0][1]
+            fp32_needed = fp32_needed or len(consumers) > 1
+        if not last.users:
+            fp32_needed = True
+        name = f"_int8_plan_{count}"
+        count += 1
+        specs[name] = None
+        modules[name] = None
+        gm.add_module(name, Int8Layer(modules[node.target], spec, relu=relu, emit=emit, want_out=fp32_needed or emit is None))
+        with graph.inserting_after(last):
+            fused = graph.call_module(name, args=(node.args[0],) if residual is None else (node.args[0], residual))
+        with graph.inserting_after(fused):
+            out = graph.call_function(operator.getitem, (fused, 0))
+            codes = graph.call_function(operator.getitem, (fused, 1))
+        for u in list(last.users):
+            if u in (out, codes):
+                continue
+            u.replace_input_with(last, codes if u in takers else out)
+        for n in reversed(chain):
+            graph.erase_node(n)
+        report.layers += 1
+        report.relu += relu
+        report.residual += residual is not None
+        report.emit += emit is not None
+        report.fp32_outputs += bool(fp32_needed or emit is None)
+    graph.eliminate_dead_code()
+    graph.lint()
+    gm.recompile()
+    gm.fusion_report = report
+    return gm

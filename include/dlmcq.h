@@ -256,6 +256,29 @@ int dlmcq_conv2d_i8_nhwc_f32(const void* x, const int8_t* w, float* out, const f
                              int64_t R, int64_t S, int32_t stride, int32_t pad, int32_t dilation,
                              int32_t x_is_unsigned, dlmcq_stream_t stream);
 
+/*
+ * The same contraction with the work that FOLLOWS a quantised layer in a frozen (inference) network folded
+ * into the epilogue, so the fp32 output, the ReLU pass, the residual add and the consumer's quantise pass stop
+ * being separate trips through HBM.  In order, per output element v = in_scale*w_scale[k]*SUM + bias[k]:
+ *   residual != NULL : v = v + residual[n,p,q,k]          (fp32 NHWC, the output's shape: the block's shortcut)
+ *   relu != 0        : v = v < 0 ? 0 : v                  (torch.relu; NaN stays NaN)
+ *   out != NULL      : out[n,p,q,k] = v
+ *   codes != NULL    : codes[n,p,q,k] = the consumer's activation code of v: forms EMULATE / QBASE /
+ *                      ZEROPOINT / SYMMETRIC of dlmcq_fake_quant_f32 with (q_scale, q_zero_point, q_lo, q_hi,
+ *                      q_ste_g) - the same arithmetic in the same order, hence the bytes that
+ *                      dlmcq_fake_quant_f32(..., DLMCQ_CODES_I8) would write for the stored fp32 tensor.
+ *                      uint8 when q_lo >= 0, else int8; -128 <= q_lo <= q_hi <= 255, q_hi - q_lo <= 255.
+ * At least one of out / codes must be given.  Replaces, for a frozen network, the chain
+ * F.conv2d -> (+ identity) -> ReLU -> next FSPTQBase.forward activation branch (FSPTQuant/base.py:108-109).
+ */
+int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float* out, const float* bias,
+                               const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                               const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
+                               int64_t R, int64_t S, int32_t stride, int32_t pad, int32_t dilation,
+                               int32_t x_is_unsigned, const float* residual, int32_t relu, void* codes,
+                               const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
+                               int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
