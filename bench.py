@@ -33,6 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 measured for a float4 copy
+MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 on the matrix cores (2x the bf16 rate; guides/MI355X_MICROARCH.md)
 
 QCFG = {  # example/quantization/FSPTQ_config.yaml:40-53: W minmax_channel s8, A minmax_tensor u8
     "weight": {"enable": True, "type": "minmax_channel", "recon_type": "None", "args": {"n_bits": 8, "signed": True}},
@@ -102,6 +103,10 @@ def main():
     ap.add_argument("--conv", choices=["int8", "fp32"], default="int8",
                     help="int8 (default): fused int8-dequant x GEMM convs/linears on the matrix cores - BASELINE configs[2] names "
                          "this path; fp32: MIOpen fp32 conv of the fake-quantised operands (the reference's own op sequence)")
+    ap.add_argument("--plan", choices=["fused", "modules"], default="fused",
+                    help="fused (default, int8 only): the frozen execution plan of dlmc.utils.fuse - ReLU, residual add and the "
+                         "next layer's activation quantiser folded into the int8 kernel's epilogue (bit-identical results); "
+                         "modules: every wrapper runs on its own, as the reference's module graph does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     args = ap.parse_args()
@@ -138,8 +143,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    args.fused = args.int8 and args.plan == "fused"
     with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):     # the first forward calibrates (observer + all-reduce)
+        model(x)                                 # the first forward calibrates (observer + all-reduce); not timed
+        if args.fused:
+            from dlmc.utils.fuse import fuse_inference
+            model = fuse_inference(model)        # scales are frozen from here on (BASELINE configs[2]: steady state)
+        for _ in range(args.warmup):
             model(x)
         K.PROFILE.enabled = True
         K.PROFILE.reset()
@@ -170,12 +180,20 @@ def main():
 
     images = args.batch * world * args.steps
 
-    def roof(name, f, kernel, note=None):
+    def roof(name, f, kernel, note=None, ops=0):
         ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] > 0 else 0.0
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel, "launches": f["launches"],
              "avg_launch_us": round(f["ms"] * 1e3 / max(f["launches"], 1), 2),
              "algorithmic_bytes_per_launch_avg": f["bytes"] // max(f["launches"], 1)}
+        if ops and f["ms"] > 0:
+            # which roofline binds: the one that needs more time at its peak
+            t_hbm, t_mfma = f["bytes"] / (HBM_PEAK_GBPS * 1e9), ops / (MFMA_I8_PEAK_TOPS * 1e12)
+            r["mfma"] = {"achieved": round(ops / (f["ms"] * 1e-3) / 1e12, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                         "frac": round(ops / (f["ms"] * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, 4)}
+            r["roofline_ms_per_step"] = {"hbm": round(t_hbm / args.steps * 1e3, 3), "mfma": round(t_mfma / args.steps * 1e3, 3)}
+            if t_mfma > t_hbm:
+                r.update(bound="mfma", achieved=r["mfma"]["achieved"], peak=MFMA_I8_PEAK_TOPS, unit="TOP/s", frac=r["mfma"]["frac"])
         if note:
             r["note"] = note
         return r
@@ -185,11 +203,22 @@ def main():
     fq_roof = roof("fq_tensor", fq, "fq_tensor_kernel<ZEROPOINT> (per-tensor activation fake-quant"
                    + (", int8 code emission: 5 B/elem)" if args.int8 else ": 8 B/elem)"))
     conv = fam.get("conv_i8", empty)
+    conv_ops = 0
+    if conv["ms"] > 0:
+        macs = sum(r[4] for r in W.layer_table(W.MODELS[args.model](), torch.zeros(1, 3, 224, 224))
+                   if r[3][1] % 64 == 0 and (len(r[3]) == 2 or r[2][1] == r[3][1]))   # the layers on the int8 kernel (dense, C % 64 == 0)
+        conv_ops = 2 * macs * args.batch * args.steps
     # `roofline` describes the kernel of this project with the largest share of the timed region
     if conv["ms"] > fq["ms"]:
-        main_roof = roof("conv_i8", conv, "conv_i8_dma_kernel (fused int8-dequant x GEMM conv/linear, fp32 NHWC out)",
-                         "algorithmic bytes = int8 input + int8 weights + fp32 output per launch; the 1x1 layers are bound by "
-                         "the fp32 output stream, the 3x3 layers by the MFMA pipeline (see conv_i8.TOPs)")
+        if args.fused:
+            main_roof = roof("conv_i8", conv, "conv_i8_dma_kernel (int8 implicit-GEMM conv/linear; epilogue: dequant + residual + ReLU + "
+                                              "next layer's activation codes)",
+                             "algorithmic bytes per launch = int8 input + int8 weights + what the epilogue moves (1 B/elem codes, "
+                             "4 B/elem fp32 output where a shortcut / pool needs it, 4 B/elem residual read)", ops=conv_ops)
+        else:
+            main_roof = roof("conv_i8", conv, "conv_i8_dma_kernel (fused int8-dequant x GEMM conv/linear, fp32 NHWC out)",
+                             "algorithmic bytes = int8 input + int8 weights + fp32 output per launch; the 1x1 layers are bound by "
+                             "the fp32 output stream, the 3x3 layers by the MFMA pipeline (see conv_i8.TOPs)", ops=conv_ops)
     else:
         main_roof = fq_roof
     qbytes = sum(f["bytes"] for k, f in fam.items() if k.startswith("fq"))
@@ -202,6 +231,7 @@ def main():
         "config": {"workload": f"{args.model} W8A8 per-channel fake-quant forward (FSPTQ forms: W minmax_channel s8, "
                                f"A minmax_tensor u8), {'BatchNorm kept' if args.keep_bn else 'BN folded first as in FSPTQuant.py:67'}, "
                                f"{'fused int8 MFMA conv/linear' if args.int8 else 'fp32 conv of the fake-quantised operands'}, "
+                               f"{'frozen execution plan (epilogue-fused ReLU / shortcut / next-layer codes), ' if args.fused else ''}"
                                f"224x224, batch {args.batch} per GPU, scales frozen",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},
         "roofline": main_roof,
@@ -213,17 +243,10 @@ def main():
                        "families": {k: {"launches": f["launches"], "GBps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)}
                                     for k, f in fam.items() if f["ms"] > 0}},
     }
-    cv = fam.get("conv_i8")
-    if cv and cv["ms"] > 0:
-        import workloads as W2
-        macs = sum(r[4] for r in W2.layer_table(W2.MODELS[args.model](), torch.zeros(1, 3, 224, 224))
-                   if r[3][1] % 64 == 0)   # the layers eligible for the int8 path (input channels % 64 == 0)
-        out["conv_i8"] = {"bound": "hbm at these shapes (fp32 outputs: 4 B written per output element vs 1 B read per input element); "
-                                   "mfma for the 3x3 layers",
-                          "launches": cv["launches"], "ms_per_step": round(cv["ms"] / args.steps, 3),
-                          "GBps": round(cv["bytes"] / (cv["ms"] * 1e-3) / 1e9, 1),
-                          "TOPs": round(2 * macs * args.batch * args.steps / (cv["ms"] * 1e-3) / 1e12, 1),
-                          "peak_TOPs_dense_i8": 5000.0}
+    if conv["ms"] > 0:
+        out["conv_i8"] = {"launches": conv["launches"], "ms_per_step": round(conv["ms"] / args.steps, 3),
+                          "GBps": round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9, 1),
+                          "TOPs": round(conv_ops / (conv["ms"] * 1e-3) / 1e12, 1), "peak_TOPs_dense_i8": MFMA_I8_PEAK_TOPS}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_batch, fold_bn=not args.keep_bn)
     print(json.dumps(out), flush=True)

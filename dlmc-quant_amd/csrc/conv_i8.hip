@@ -213,21 +213,55 @@ struct ConvEpi {
 };
 
 struct EpiQuant {   // the consumer's constants, resolved once per thread
-  float dv, of, lo, hi;
-  int form;
-  __device__ __forceinline__ EpiQuant(const ConvEpi& ep) : dv(1.0f), of(0.0f), lo(ep.q_lo), hi(ep.q_hi), form(ep.q_form) {
+  float dv, rdv, of, zadd, lo, hi;
+  bool sgn;
+  __device__ __forceinline__ EpiQuant(const ConvEpi& ep)
+      : dv(1.0f), rdv(1.0f), of(0.0f), zadd(0.0f), lo(ep.q_lo), hi(ep.q_hi), sgn(ep.q_lo < 0.0f) {
     if (!ep.codes) return;
     const float s = ep.q_scale[0];
-    of = ep.q_zp ? ep.q_zp[0] : 0.0f;
+    const float z = ep.q_zp ? ep.q_zp[0] : 0.0f;
+    const int form = ep.q_form;
     dv = form == DLMCQ_FORM_EMULATE ? s + 1e-7f : (form == DLMCQ_FORM_QBASE ? ste_scale(s, ep.q_g) : s);
+    // EMULATE / QBASE divide (v - offset); ZEROPOINT adds the zero point after rounding; v - 0 is v, r + 0 is r
+    of = (form == DLMCQ_FORM_EMULATE || form == DLMCQ_FORM_QBASE) ? z : 0.0f;
+    zadd = form == DLMCQ_FORM_ZEROPOINT ? z : 0.0f;
+    // the fast path below is proven for a well-scaled divisor and a byte-sized zero point; anything else (and NaN)
+    // makes rdv NaN, which routes every element to the exact division
+    const bool tame = __builtin_fabsf(dv) >= 0x1p-100f && __builtin_fabsf(dv) <= 0x1p100f && __builtin_fabsf(zadd) <= 256.0f;
+    rdv = tame ? 1.0f / dv : __builtin_nanf("");
   }
-  __device__ __forceinline__ uint32_t code(float v) const {
-    float q;
-    if (form == DLMCQ_FORM_EMULATE) q = clamp_nan(__builtin_rintf((v - of) / dv), lo, hi);
-    else if (form == DLMCQ_FORM_QBASE) q = ste_round(clamp_nan((v - of) / dv, lo, hi));
-    else if (form == DLMCQ_FORM_ZEROPOINT) q = clamp_nan(ste_round(v / dv) + of, lo, hi);
-    else q = clamp_nan(ste_round(v / dv), lo, hi);
+  // All four forms reduce to  code = clamp(rint(d) + zadd, lo, hi)  with d = fl(u / dv), u = v - of
+  // (rint(clamp(d)) = clamp(rint(d)) for integral bounds, and the STE identity (r - d) + d returns r exactly;
+  //  a NaN becomes code 0, as code_of does it in the stand-alone kernels).
+  __device__ __forceinline__ uint32_t exact(float v) const {
+    const float q = clamp_nan(__builtin_rintf((v - of) / dv) + zadd, lo, hi);
     return (uint32_t)(code_of(q) & 0xff);
+  }
+  // A correctly rounded division costs ~25 VALU operations per element - more than everything else in the epilogue -
+  // so d is replaced by t = fl(u * fl(1/dv)), which differs from d by less than 2^-22 |t|.  For |t| <= 512 that is
+  // below 2^-13: unless t lies within 2^-12 of a rounding tie (x.5), rint(t) = rint(d); for |t| > 512 both saturate
+  // to the same bound (|zadd| <= 256, |lo|, |hi| <= 255).  Ties that close, infinities and NaNs (about one element in
+  // 2000) take the exact division, four elements at a time.  Bit-identical codes at ~10 operations per element.
+  __device__ __forceinline__ uint32_t code4(const f32x4& v) const {
+    const float t0 = (v.x - of) * rdv, t1 = (v.y - of) * rdv, t2 = (v.z - of) * rdv, t3 = (v.w - of) * rdv;
+    const float r0 = __builtin_rintf(t0), r1 = __builtin_rintf(t1), r2 = __builtin_rintf(t2), r3 = __builtin_rintf(t3);
+    // worst distance from an integer; a non-finite input poisons it through (sum * 0), max() alone would drop a NaN
+    float worst = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t0 - r0), __builtin_fabsf(t1 - r1)),
+                                  __builtin_fmaxf(__builtin_fabsf(t2 - r2), __builtin_fabsf(t3 - r3)));
+    worst = worst + ((t0 + t1) + (t2 + t3)) * 0.0f;
+    if (!(worst < 0.5f - 0x1p-12f)) return exact(v.x) | (exact(v.y) << 8) | (exact(v.z) << 16) | (exact(v.w) << 24);
+    float q0 = __builtin_amdgcn_fmed3f(r0 + zadd, lo, hi), q1 = __builtin_amdgcn_fmed3f(r1 + zadd, lo, hi);
+    float q2 = __builtin_amdgcn_fmed3f(r2 + zadd, lo, hi), q3 = __builtin_amdgcn_fmed3f(r3 + zadd, lo, hi);
+    if (sgn) {   // two's-complement byte of a negative code
+      q0 = q0 < 0.0f ? q0 + 256.0f : q0;
+      q1 = q1 < 0.0f ? q1 + 256.0f : q1;
+      q2 = q2 < 0.0f ? q2 + 256.0f : q2;
+      q3 = q3 < 0.0f ? q3 + 256.0f : q3;
+    }
+    uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(q0, 0, 0u);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(q1, 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(q2, 2, w);
+    return __builtin_amdgcn_cvt_pk_u8_f32(q3, 3, w);
   }
 };
 
@@ -245,7 +279,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // ABL (timing-only ablations, never shipped): 1 = no operand DMA inside the K loop, 2 = no MFMA, 4 = no LDS fragment reads
 template <int BM, int BN, int NBUF = 3, int BK = CV_BK, int ABL = 0>
-__global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+__global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                          float* __restrict__ out, const float* __restrict__ bias,
                                                          const int32_t* __restrict__ wsum,
                                                          const float* __restrict__ s_in,
@@ -406,6 +440,17 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
     const int er = lane >> 4, ec = (lane & 15) * 4;
 #pragma unroll
     for (int h = 0; h < NT / 2 + (NT & 1); ++h) {
+      // the shortcut tile is requested first: its latency hides behind the dequantise-and-stage phase below
+      f32x4 idt[8];
+      if (ep.residual) {
+        const int colr = n0 + h * 64 + ec;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int64_t row = m0 + wrow0 + it * 4 + er;
+          idt[it] = (row < g.M && colr < g.K) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ep.residual + row * g.K + colr))
+                                              : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+      }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int j = h * 2 + jj;
@@ -431,15 +476,11 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
         f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * EP_LD + ec);
         if (row < g.M && col < g.K) {
           const int64_t at = row * g.K + col;
-          if (ep.residual) {
-            const f32x4 idt = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ep.residual + at));
-            v = f32x4{v.x + idt.x, v.y + idt.y, v.z + idt.z, v.w + idt.w};
-          }
+          if (ep.residual) v = f32x4{v.x + idt[it].x, v.y + idt[it].y, v.z + idt[it].z, v.w + idt[it].w};
           if (ep.relu) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
           if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
           if (ep.codes)
-            __builtin_nontemporal_store(eq.code(v.x) | (eq.code(v.y) << 8) | (eq.code(v.z) << 16) | (eq.code(v.w) << 24),
-                                        reinterpret_cast<uint32_t*>(ep.codes + at));
+            __builtin_nontemporal_store(eq.code4(v), reinterpret_cast<uint32_t*>(ep.codes + at));
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the stage
@@ -464,7 +505,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 1)) void conv_i8_dma_kernel(c
         if (ep.residual) v = v + ep.residual[at];
         if (ep.relu) v = relu_nan(v);
         if (out) __builtin_nontemporal_store(v, out + at);
-        if (ep.codes) ep.codes[at] = (uint8_t)eq.code(v);
+        if (ep.codes) ep.codes[at] = (uint8_t)eq.exact(v);
       }
   }
 }
