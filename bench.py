@@ -76,6 +76,8 @@ def cpu_baseline(batch, budget_s=20.0, fold_bn=True):
                     setattr(m, cname, torch.nn.Identity())
     model = port_model(model, "FSPTQ")
     x = torch.randn(batch, 3, 224, 224)
+    if halfnormal:
+        x = torch.relu(x)
     with torch.no_grad():
         t0 = time.perf_counter()
         model(x)                      # calibration + warm-up
@@ -107,6 +109,10 @@ def main():
                     help="fused (default, int8 only): the frozen execution plan of dlmc.utils.fuse - ReLU, residual add and the "
                          "next layer's activation quantiser folded into the int8 kernel's epilogue (bit-identical results); "
                          "modules: every wrapper runs on its own, as the reference's module graph does")
+    ap.add_argument("--input", choices=["halfnormal", "normal"], default="halfnormal",
+                    help="synthetic pixels: relu(N(0,1)) (default; SURVEY.md 8(d): the input of unsigned-activation configs, "
+                         "min = 0 -> integer zero point) or N(0,1) (the u8 zero point of the first layer is then the negative "
+                         "non-integer minimum, as the reference computes it, and that layer keeps its fp32 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     args = ap.parse_args()
@@ -135,6 +141,8 @@ def main():
     quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=args.int8)
     g = torch.Generator(device=dev).manual_seed(2333 + rank)
     x = torch.randn(args.batch, 3, 224, 224, device=dev, generator=g)
+    if args.input == "halfnormal":
+        x = torch.relu(x)
     if args.int8:
         x = x.contiguous(memory_format=torch.channels_last)   # activations travel NHWC for the matrix cores
 
@@ -232,7 +240,7 @@ def main():
                                f"A minmax_tensor u8), {'BatchNorm kept' if args.keep_bn else 'BN folded first as in FSPTQuant.py:67'}, "
                                f"{'fused int8 MFMA conv/linear' if args.int8 else 'fp32 conv of the fake-quantised operands'}, "
                                f"{'frozen execution plan (epilogue-fused ReLU / shortcut / next-layer codes), ' if args.fused else ''}"
-                               f"224x224, batch {args.batch} per GPU, scales frozen",
+                               f"224x224 {'relu(N(0,1))' if args.input == 'halfnormal' else 'N(0,1)'} pixels, batch {args.batch} per GPU, scales frozen",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},
         "roofline": main_roof,
         "roofline_fake_quant": fq_roof,
@@ -248,7 +256,7 @@ def main():
                           "GBps": round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9, 1),
                           "TOPs": round(conv_ops / (conv["ms"] * 1e-3) / 1e12, 1), "peak_TOPs_dense_i8": MFMA_I8_PEAK_TOPS}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_batch, fold_bn=not args.keep_bn)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_batch, fold_bn=not args.keep_bn, halfnormal=args.input == "halfnormal")
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,341 @@
+// The network's first convolution (3 input channels: 7x7/2 in ResNet, 3x3/2 in RepVGG / MobileOne) on the matrix
+// cores, and the max-pool that follows it, in the integer-code domain.
+//
+// The generic int8 kernel (conv_i8.hip) steps its reduction 64 input channels at a time, so a 3-channel layer
+// cannot use it; the reference (and the module path of this build) run it as an fp32 convolution of the
+// fake-quantised image, followed by separate bias-add, ReLU, max-pool and next-layer quantise passes over a
+// 64-channel 112x112 fp32 tensor - at batch 512 that is 3.8 ms of a 13 ms forward for 3 % of the MACs.
+//
+// Layout trick: quantise the image into a zero-point-PADDED NHWC buffer with 4 bytes per pixel
+// ([N][H+2p][W+2p][4], border = the code of x' = 0, 4th byte unused).  For an output pixel and a filter row r the
+// S <= 8 taps x 4 bytes it needs are then 32 CONTIGUOUS, 4-byte-aligned bytes - exactly one K = 32 operand of
+// v_mfma_i32_32x32x32_i8 (lanes 0-31: taps 0-3, lanes 32-63: taps 4-7), loaded straight from global memory with no
+// bounds checks (the border is physically there) and no LDS staging.  Taps beyond S and the 4th channel meet zero
+// weights.  One MFMA per filter row per 32 output channels; the weights of all rows live in registers for the whole
+// (persistent) kernel.  Epilogue as in conv_i8.hip: exact int32 sum -> one rounding chain -> bias, ReLU, and the
+// consumer's activation code (conv_epilogue.h).
+//
+// Max-pool commutes with the (monotone) quantiser: code(max(v)) = max(code(v)).  So the pool runs on the codes,
+// 1 byte per element instead of 4, and never sees fp32.
+#include "conv_epilogue.h"
+
+namespace dlmcq {
+
+// ---------------------------------------------------------------- image -> padded NHWC4 codes
+struct ImgGeom {
+  int N, C, H, W, pad, Hp, Wp;
+  int64_t sn, sc, sh, sw;   // element strides of the fp32 input (any memory format)
+  FastDiv wdiv, hdiv;
+};
+
+__global__ __launch_bounds__(DLMCQ_BLOCK) void quantize_pad_nhwc4_kernel(const float* __restrict__ x, uint32_t* __restrict__ out,
+                                                                         const float* __restrict__ scale,
+                                                                         const float* __restrict__ zp, ImgGeom g, float lo,
+                                                                         float hi, int form, float ste_g) {
+  const float s = scale[0], z = zp ? zp[0] : 0.0f;
+  const float dv = form == DLMCQ_FORM_EMULATE ? s + 1e-7f : (form == DLMCQ_FORM_QBASE ? ste_scale(s, ste_g) : s);
+  const float of = (form == DLMCQ_FORM_EMULATE || form == DLMCQ_FORM_QBASE) ? z : 0.0f;
+  const float zadd = form == DLMCQ_FORM_ZEROPOINT ? z : 0.0f;
+  auto code = [&](float v) -> uint32_t {   // the four forms of fq_one, reduced as in conv_epilogue.h (exact division)
+    const float q = clamp_nan(__builtin_rintf((v - of) / dv) + zadd, lo, hi);
+    return (uint32_t)(code_of(q) & 0xff);
+  };
+  const uint32_t border = code(0.0f) * 0x00010101u;   // x' = 0 (zero padding of the fake-quantised image)
+  const int64_t total = (int64_t)g.N * g.Hp * g.Wp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t t = fdiv((uint32_t)i, g.wdiv);
+    const int wp = (int)((uint32_t)i - t * (uint32_t)g.Wp);
+    const uint32_t n = fdiv(t, g.hdiv);
+    const int hp = (int)(t - n * (uint32_t)g.Hp);
+    const int h = hp - g.pad, w = wp - g.pad;
+    uint32_t px = border;
+    if (h >= 0 && h < g.H && w >= 0 && w < g.W) {
+      const float* p = x + (int64_t)n * g.sn + (int64_t)h * g.sh + (int64_t)w * g.sw;
+      px = 0;
+      for (int c = 0; c < g.C; ++c) px |= code(p[c * g.sc]) << (8 * c);
+    }
+    out[i] = px;
+  }
+}
+
+// ------------------------------------------------------------------ weights -> [K][R][8 taps][4]
+__global__ __launch_bounds__(DLMCQ_BLOCK) void quantize_weight_stem_kernel(const float* __restrict__ w, int8_t* __restrict__ wq,
+                                                                           int32_t* __restrict__ wsum,
+                                                                           const float* __restrict__ scale, int C, int R, int S,
+                                                                           float lo, float hi) {
+  // one block per output channel; SYMMETRIC form (FSPTQuant/base.py:149-152), as quantize_weight_krsc_kernel
+  const int k = blockIdx.x;
+  const float s = scale[k];
+  __shared__ int part[DLMCQ_BLOCK / DLMCQ_WAVE];
+  int sum = 0;
+  for (int i = threadIdx.x; i < R * 32; i += blockDim.x) {
+    const int r = i >> 5, tap = (i >> 2) & 7, c = i & 3;
+    int q = 0;
+    if (tap < S && c < C) {
+      const float v = w[(((int64_t)k * C + c) * R + r) * S + tap];
+      q = code_of(clamp_nan(ste_round(v / s), lo, hi));
+    }
+    wq[(int64_t)k * R * 32 + i] = (int8_t)q;
+    sum += q;
+  }
+  for (int o = DLMCQ_WAVE / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, DLMCQ_WAVE);
+  if ((threadIdx.x & (DLMCQ_WAVE - 1)) == 0) part[threadIdx.x / DLMCQ_WAVE] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int i = 0; i < DLMCQ_BLOCK / DLMCQ_WAVE; ++i) t += part[i];
+    wsum[k] = t;
+  }
+}
+
+// ----------------------------------------------------------------------------- the convolution
+struct StemGeom {
+  int N, Hp, Wp, K, R, stride, P, Q;
+  int64_t M;     // N*P*Q
+  int ntiles;    // ceil(M / 32)
+  FastDiv qdiv, pdiv;
+};
+
+constexpr int ST_MAXR = 7;
+constexpr int ST_EP_LD = 68;   // floats per staged row (64 + 4 pad)
+
+// One wave = one 32-pixel x 64-channel output tile at a time (grid-stride over tiles); 4 independent waves per
+// workgroup.  blockIdx.y selects the 64-channel slab.
+template <int R>
+__global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                           float* __restrict__ out, const float* __restrict__ bias,
+                                                           const int32_t* __restrict__ wsum, const float* __restrict__ s_in,
+                                                           const float* __restrict__ zp_in, const float* __restrict__ s_w,
+                                                           StemGeom g, int shift, ConvEpi ep) {
+  __shared__ __attribute__((aligned(16))) float stage[4 * 32 * ST_EP_LD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n0 = blockIdx.y * 64;
+  const int hsel = lane >> 5;
+  const uint32_t xorw = shift ? 0x80808080u : 0u;
+  const float zpf = zp_in ? zp_in[0] : 0.0f;
+  const int zpi = (int)__builtin_rintf(zpf);
+  const float sin = s_in[0];
+  const EpiQuant eq(ep);
+
+  // weights of this slab: fragment (r, j) = 16 bytes of channel n0 + j*32 + (lane & 31), taps hsel*4 .. +3
+  i32x4 bf[R][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = n0 + j * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      bf[r][j] = k < g.K ? *reinterpret_cast<const i32x4*>(w + ((int64_t)k * R + r) * 32 + hsel * 16) : i32x4{0, 0, 0, 0};
+  }
+  float mult[2], bv[2];
+  int corr[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = n0 + j * 32 + (lane & 31);
+    const bool ok = k < g.K;
+    mult[j] = ok ? sin * s_w[k] : 0.0f;
+    corr[j] = ok ? (shift - zpi) * wsum[k] : 0;
+    bv[j] = (ok && bias) ? bias[k] : 0.0f;
+  }
+  float* stg = stage + wave * (32 * ST_EP_LD);
+  const int er = lane >> 4, ec = (lane & 15) * 4;
+  const int rowbytes = g.Wp * 4;
+
+  for (int tile = blockIdx.x * 4 + wave; tile < g.ntiles; tile += gridDim.x * 4) {
+    const int64_t m0 = (int64_t)tile * 32;
+    int64_t m = m0 + (lane & 31);
+    if (m >= g.M) m = g.M - 1;                       // ragged last tile: recompute a valid pixel, never stored
+    const uint32_t t = fdiv((uint32_t)m, g.qdiv);
+    const int q = (int)((uint32_t)m - t * (uint32_t)g.Q);
+    const uint32_t n = fdiv(t, g.pdiv);
+    const int p = (int)(t - n * (uint32_t)g.P);
+    const uint8_t* src = x + (((int64_t)n * g.Hp + (int64_t)p * g.stride) * g.Wp + (int64_t)q * g.stride) * 4 + hsel * 16;
+    i32x4 af[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) af[r] = *reinterpret_cast<const i32x4*>(src + (int64_t)r * rowbytes);
+    i32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][i] = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const i32x4 a = i32x4{(int)(af[r].x ^ xorw), (int)(af[r].y ^ xorw), (int)(af[r].z ^ xorw), (int)(af[r].w ^ xorw)};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[r][j], acc[j], 0, 0, 0);
+    }
+    // ---- epilogue: accumulator layout (lane = channel, register = pixel) -> pixel-major through this wave's stage ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2) + 4 * hsel;
+        stg[r * ST_EP_LD + j * 32 + (lane & 31)] = (float)(acc[j][i] + corr[j]) * mult[j] + bv[j];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave reads back only what it wrote itself
+    const int col = n0 + ec;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 4 + er;
+      const int64_t row = m0 + r;
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * ST_EP_LD + ec);
+      if (row < g.M && col < g.K) {
+        const int64_t at = row * g.K + col;
+        if (ep.relu) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
+        if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
+        if (ep.codes) __builtin_nontemporal_store(eq.code4(v), reinterpret_cast<uint32_t*>(ep.codes + at));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next tile overwrites the stage
+  }
+}
+
+// ------------------------------------------------------------------------- max-pool on codes
+struct PoolGeom {
+  int N, H, W, C4, k, stride, pad, P, Q;   // C4 = C / 4 (dwords per pixel)
+  FastDiv cdiv, qdiv, pdiv;
+};
+
+__global__ __launch_bounds__(DLMCQ_BLOCK) void maxpool_codes_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ y,
+                                                                    PoolGeom g, uint32_t flip) {
+  // one thread = 4 channels of one output pixel; signed codes are compared as unsigned after flipping the sign bit
+  const int64_t total = (int64_t)g.N * g.P * g.Q * g.C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t pix = fdiv((uint32_t)i, g.cdiv);
+    const int c4 = (int)((uint32_t)i - pix * (uint32_t)g.C4);
+    const uint32_t t = fdiv(pix, g.qdiv);
+    const int q = (int)(pix - t * (uint32_t)g.Q);
+    const uint32_t n = fdiv(t, g.pdiv);
+    const int p = (int)(t - n * (uint32_t)g.P);
+    const int h0 = p * g.stride - g.pad, w0 = q * g.stride - g.pad;
+    uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;   // padding never wins: the lowest code is 0 after the flip
+    for (int dh = 0; dh < g.k; ++dh) {
+      const int h = h0 + dh;
+      if (h < 0 || h >= g.H) continue;
+      for (int dw = 0; dw < g.k; ++dw) {
+        const int w = w0 + dw;
+        if (w < 0 || w >= g.W) continue;
+        const uint32_t v = x[(((int64_t)n * g.H + h) * g.W + w) * g.C4 + c4] ^ flip;
+        b0 = max(b0, v & 0xffu);
+        b1 = max(b1, (v >> 8) & 0xffu);
+        b2 = max(b2, (v >> 16) & 0xffu);
+        b3 = max(b3, v >> 24);
+      }
+    }
+    y[i] = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) ^ flip;
+  }
+}
+
+}  // namespace dlmcq
+
+using namespace dlmcq;
+
+extern "C" int dlmcq_quantize_pad_nhwc4(const float* x, void* out, const float* scale, const float* zero_point, int64_t N,
+                                        int64_t C, int64_t H, int64_t W, int64_t stride_n, int64_t stride_c, int64_t stride_h,
+                                        int64_t stride_w, int32_t pad, int32_t lo, int32_t hi, int32_t form, float ste_g,
+                                        dlmcq_stream_t stream) {
+  if (N < 0 || C < 1 || C > 4 || H < 1 || W < 1 || pad < 0 || lo > hi || lo < -128 || hi > 255 || hi - lo > 255)
+    return DLMCQ_EINVAL;
+  if (form < DLMCQ_FORM_EMULATE || form > DLMCQ_FORM_SYMMETRIC) return DLMCQ_EINVAL;
+  if (N == 0) return DLMCQ_OK;
+  if (!x || !out || !scale) return DLMCQ_EINVAL;
+  if (!aligned4(out)) return DLMCQ_EALIGN;
+  ImgGeom g;
+  g.N = (int)N; g.C = (int)C; g.H = (int)H; g.W = (int)W; g.pad = pad;
+  g.Hp = (int)H + 2 * pad; g.Wp = (int)W + 2 * pad;
+  g.sn = stride_n; g.sc = stride_c; g.sh = stride_h; g.sw = stride_w;
+  const int64_t total = N * g.Hp * g.Wp;
+  if (total >= (1ll << 31)) return DLMCQ_ERANGE;
+  g.wdiv = make_fastdiv((uint32_t)g.Wp);
+  g.hdiv = make_fastdiv((uint32_t)g.Hp);
+  const int64_t blocks = (total + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
+  hipLaunchKernelGGL(quantize_pad_nhwc4_kernel, dim3((uint32_t)(blocks < 16384 ? blocks : 16384)), dim3(DLMCQ_BLOCK), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, static_cast<uint32_t*>(out), scale, zero_point, g, (float)lo,
+                     (float)hi, form, ste_g);
+  return launch_status();
+}
+
+extern "C" int dlmcq_quantize_weight_stem_i8(const float* w, int8_t* wq, int32_t* wsum, const float* scale, int64_t K,
+                                             int64_t C, int64_t R, int64_t S, int32_t lo, int32_t hi,
+                                             dlmcq_stream_t stream) {
+  if (K < 1 || C < 1 || C > 4 || R < 1 || R > ST_MAXR || S < 1 || S > 8 || lo > hi || lo < -128 || hi > 127)
+    return DLMCQ_EINVAL;
+  if (!w || !wq || !wsum || !scale) return DLMCQ_EINVAL;
+  if (!aligned16(wq)) return DLMCQ_EALIGN;
+  hipLaunchKernelGGL(quantize_weight_stem_kernel, dim3((uint32_t)K), dim3(DLMCQ_BLOCK), 0,
+                     reinterpret_cast<hipStream_t>(stream), w, wq, wsum, scale, (int)C, (int)R, (int)S, (float)lo, (float)hi);
+  return launch_status();
+}
+
+extern "C" int dlmcq_conv2d_i8_stem_fused(const void* xpad, const int8_t* w, float* out, const float* bias,
+                                          const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                                          const float* w_scale, int64_t N, int64_t Hp, int64_t Wp, int64_t K, int64_t R,
+                                          int64_t S, int32_t stride, int32_t x_is_unsigned, int32_t relu, void* codes,
+                                          const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
+                                          int32_t q_form, float q_ste_g, dlmcq_stream_t stream) {
+  if (N < 0 || Hp < 1 || Wp < 1 || K < 1 || R < 1 || R > ST_MAXR || S < 1 || S > 8 || stride < 1) return DLMCQ_EINVAL;
+  if (Hp < R || Wp < S || (K & 3)) return DLMCQ_EINVAL;
+  const int64_t P = (Hp - R) / stride + 1, Q = (Wp - S) / stride + 1;
+  const int64_t M = N * P * Q;
+  if (M == 0) return DLMCQ_OK;
+  if (!xpad || !w || !(out || codes) || !wsum || !in_scale || !w_scale) return DLMCQ_EINVAL;
+  if (codes && (!q_scale || q_lo > q_hi || q_lo < -128 || q_hi > 255 || q_hi - q_lo > 255 || q_form < DLMCQ_FORM_EMULATE ||
+                q_form > DLMCQ_FORM_SYMMETRIC))
+    return DLMCQ_EINVAL;
+  if (!aligned4(xpad) || !aligned16(w) || (out && !aligned16(out)) || (codes && !aligned4(codes))) return DLMCQ_EALIGN;
+  if (M >= (1ll << 31) || N * Hp * Wp >= (1ll << 31)) return DLMCQ_ERANGE;
+  StemGeom g;
+  g.N = (int)N; g.Hp = (int)Hp; g.Wp = (int)Wp; g.K = (int)K; g.R = (int)R; g.stride = stride; g.P = (int)P; g.Q = (int)Q;
+  g.M = M;
+  g.ntiles = (int)((M + 31) / 32);
+  g.qdiv = make_fastdiv((uint32_t)Q);
+  g.pdiv = make_fastdiv((uint32_t)P);
+  ConvEpi ep{};
+  ep.relu = relu != 0;
+  ep.codes = static_cast<uint8_t*>(codes);
+  ep.q_scale = q_scale;
+  ep.q_zp = q_zero_point;
+  ep.q_lo = (float)q_lo;
+  ep.q_hi = (float)q_hi;
+  ep.q_g = q_ste_g;
+  ep.q_form = q_form;
+  const int wgs = (g.ntiles + 3) / 4;
+  const dim3 grid((uint32_t)(wgs < 2048 ? wgs : 2048), (uint32_t)((K + 63) / 64));
+  const int shift = x_is_unsigned ? 128 : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const uint8_t* xs = static_cast<const uint8_t*>(xpad);
+#define DLMCQ_STEM_ARGS grid, dim3(256), 0, st, xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep
+  switch ((int)R) {
+    case 1: hipLaunchKernelGGL((conv_stem_i8_kernel<1>), DLMCQ_STEM_ARGS); break;
+    case 2: hipLaunchKernelGGL((conv_stem_i8_kernel<2>), DLMCQ_STEM_ARGS); break;
+    case 3: hipLaunchKernelGGL((conv_stem_i8_kernel<3>), DLMCQ_STEM_ARGS); break;
+    case 4: hipLaunchKernelGGL((conv_stem_i8_kernel<4>), DLMCQ_STEM_ARGS); break;
+    case 5: hipLaunchKernelGGL((conv_stem_i8_kernel<5>), DLMCQ_STEM_ARGS); break;
+    case 6: hipLaunchKernelGGL((conv_stem_i8_kernel<6>), DLMCQ_STEM_ARGS); break;
+    default: hipLaunchKernelGGL((conv_stem_i8_kernel<7>), DLMCQ_STEM_ARGS); break;
+  }
+#undef DLMCQ_STEM_ARGS
+  return launch_status();
+}
+
+extern "C" int dlmcq_maxpool_codes_nhwc(const void* x, void* y, int64_t N, int64_t H, int64_t W, int64_t C, int32_t kernel,
+                                        int32_t stride, int32_t pad, int32_t x_is_unsigned, dlmcq_stream_t stream) {
+  if (N < 0 || H < 1 || W < 1 || C < 4 || (C & 3) || kernel < 1 || stride < 1 || pad < 0 || 2 * pad > kernel) return DLMCQ_EINVAL;
+  const int64_t P = (H + 2 * pad - kernel) / stride + 1, Q = (W + 2 * pad - kernel) / stride + 1;
+  if (P < 1 || Q < 1) return DLMCQ_EINVAL;
+  if (N == 0) return DLMCQ_OK;
+  if (!x || !y) return DLMCQ_EINVAL;
+  if (!aligned4(x) || !aligned4(y)) return DLMCQ_EALIGN;
+  const int64_t total = N * P * Q * (C / 4);
+  if (total >= (1ll << 31) || N * H * W * (C / 4) >= (1ll << 31)) return DLMCQ_ERANGE;
+  PoolGeom g;
+  g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C4 = (int)(C / 4); g.k = kernel; g.stride = stride; g.pad = pad;
+  g.P = (int)P; g.Q = (int)Q;
+  g.cdiv = make_fastdiv((uint32_t)g.C4);
+  g.qdiv = make_fastdiv((uint32_t)Q);
+  g.pdiv = make_fastdiv((uint32_t)P);
+  const int64_t blocks = (total + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
+  hipLaunchKernelGGL(maxpool_codes_kernel, dim3((uint32_t)(blocks < 65536 ? blocks : 65536)), dim3(DLMCQ_BLOCK), 0,
+                     reinterpret_cast<hipStream_t>(stream), static_cast<const uint32_t*>(x), static_cast<uint32_t*>(y), g,
+                     x_is_unsigned ? 0u : 0x80808080u);
+  return launch_status();
+}

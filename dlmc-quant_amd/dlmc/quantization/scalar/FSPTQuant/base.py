@@ -18,7 +18,7 @@ from torch.nn import Module
 from .... import _native as N
 from .. import kernels as K
 from .. import ops
-from .._wrapper import InitState, fake_quant, int8_forward, int8_gemm_default, int8_layer_ok, set_scale
+from .._wrapper import InitState, fake_quant, int8_forward, int8_gemm_default, int8_kind, set_scale
 from ..utils import get_qrange
 
 
@@ -89,7 +89,7 @@ class FSPTQBase(Module):
             return False
         if self.qconfig["weight"].get("recon_type") in ("adaround", "dist_recon") or self.in_scale.numel() != 1:
             return False
-        if not (int8_layer_ok(self) and self.wt_min_val >= -128 and self.wt_max_val <= 127):
+        if not (int8_kind(self) is not None and self.wt_min_val >= -128 and self.wt_max_val <= 127):
             return False
         if not (0 <= self.in_min_val and self.in_max_val <= 255) and not (-128 <= self.in_min_val and self.in_max_val <= 127):
             return False

@@ -172,6 +172,22 @@ def int8_layer_ok(mod):
     return w.shape[1] % 64 == 0 and sq(mod.stride) and sq(mod.padding) and sq(mod.dilation)
 
 
+def int8_stem_ok(mod):
+    """Static eligibility for the first-layer kernel (csrc/conv_stem_i8.hip): a dense zero-padded convolution with
+    <= 4 input channels, <= 7 filter rows, <= 8 taps per row, dilation 1, square stride / padding."""
+    w = mod.weight
+    if w.dim() != 4 or mod.groups != 1 or mod.padding_mode != "zeros" or isinstance(mod.padding, str):
+        return False
+    sq = lambda t: len(set(t)) == 1  # noqa: E731
+    return (w.shape[1] <= 4 and w.shape[2] <= 7 and w.shape[3] <= 8 and w.shape[0] % 4 == 0 and sq(mod.stride)
+            and sq(mod.padding) and tuple(mod.dilation) == (1, 1))
+
+
+def int8_kind(mod):
+    """"gemm" (conv_i8.hip), "stem" (conv_stem_i8.hip) or None."""
+    return "gemm" if int8_layer_ok(mod) else ("stem" if int8_stem_ok(mod) else None)
+
+
 def ste_scale_value(scale, g):
     """Forward value of the reference's grad_scale on a (tiny) scale tensor: (s - s*g) + s*g."""
     sg = scale.detach() * g
@@ -182,6 +198,12 @@ def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, 
     """Quantise the activation to integer codes (one pass, 4 B read + 1 B written per element), quantise the
     weight to KRSC int8, and contract on v_mfma_i32_32x32x32_i8 with the dequantisation fused into the epilogue.
     Same mathematical result as F.conv2d(fake_quant(x), fake_quant(w), bias); activations travel channels_last."""
+    if not int8_layer_ok(mod):   # the 3-channel first layer: padded NHWC4 codes, one MFMA per filter row
+        xpad = K.quantize_pad_nhwc4(input, in_scale.detach(), in_zp, in_lo, in_hi, act_form, mod.padding[0], g=g_in)
+        if g_in:
+            in_scale = ste_scale_value(in_scale, g_in)
+        wq, wsum = K.quantize_weight_stem(mod.weight, wt_scale, wt_lo, wt_hi)
+        return K.conv2d_i8_stem(xpad, wq, wsum, mod.bias, in_scale, in_zp, wt_scale, mod.weight.shape[3], stride=mod.stride[0])
     if input.dim() == 4 and not input.is_contiguous(memory_format=torch.channels_last):
         input = input.contiguous(memory_format=torch.channels_last)   # one transposing copy, at the model's first int8 layer
     _, codes = K.fake_quant(input, in_scale.detach(), in_zp, in_lo, in_hi, act_form, g=g_in, codes="i8", want_y=False)

@@ -367,6 +367,89 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
     return out
 
 
+def quantize_pad_nhwc4(x, scale, zero_point, lo, hi, form, pad, g=0.0):
+    """Image batch (N, C <= 4, H, W) fp32, any memory format -> activation codes in a zero-point-padded NHWC
+    buffer, 4 bytes per pixel: uint8/int8 tensor (N, H + 2 pad, W + 2 pad, 4) (a view of a slightly larger
+    allocation: the stem kernel over-reads up to 32 bytes)."""
+    N.require_gpu(x)
+    if x.dim() != 4 or x.shape[1] > 4 or x.dtype != torch.float32:
+        raise ValueError("quantize_pad_nhwc4 takes an fp32 (N, C <= 4, H, W) tensor")
+    n, c, h, w = x.shape
+    hp, wp = h + 2 * pad, w + 2 * pad
+    flat = torch.empty(n * hp * wp * 4 + 32, dtype=torch.uint8 if lo >= 0 else torch.int8, device=x.device)
+    scale = _f32c(scale.detach(), x).reshape(-1)
+    zero_point = None if zero_point is None else _f32c(zero_point, x).reshape(-1)
+    PROFILE.launch("fq_image", x.numel() * 4 + n * hp * wp * 4, lambda: N.check(N.lib.dlmcq_quantize_pad_nhwc4(
+        N.ptr(x), N.ptr(flat), N.ptr(scale), N.ptr(zero_point), n, c, h, w, *x.stride(), int(pad), int(lo), int(hi), int(form),
+        float(g), N.stream_ptr())))
+    return flat[:n * hp * wp * 4].view(n, hp, wp, 4)
+
+
+def quantize_weight_stem(w, scale, lo, hi):
+    """fp32 KCRS weights of a C <= 4 layer -> (int8 [K, R, 8, 4] zero-filled, int32 per-channel code sums)."""
+    N.require_gpu(w)
+    w = w.detach().contiguous()
+    K_, C, R, S = w.shape
+    scale = _f32c(scale.detach(), w).reshape(-1)
+    if scale.numel() == 1:
+        scale = scale.expand(K_).contiguous()
+    wq = torch.empty((K_, R, 8, 4), dtype=torch.int8, device=w.device)
+    wsum = torch.empty(K_, dtype=torch.int32, device=w.device)
+    N.check(N.lib.dlmcq_quantize_weight_stem_i8(N.ptr(w), N.ptr(wq), N.ptr(wsum), N.ptr(scale), K_, C, R, S, int(lo), int(hi),
+                                                N.stream_ptr()))
+    return wq, wsum
+
+
+def conv2d_i8_stem(xpad, wq, wsum, bias, in_scale, in_zp, w_scale, S, stride=1, relu=False, emit=None, want_out=True):
+    """The first-layer convolution on padded NHWC4 codes (quantize_pad_nhwc4 / quantize_weight_stem).  Returns fp32
+    (N, K, P, Q) channels_last, or `(out, codes)` with `emit` (see conv2d_i8)."""
+    N.require_gpu(xpad, wq)
+    n, hp, wp, _ = xpad.shape
+    K_, R = wq.shape[0], wq.shape[1]
+    P, Q = (hp - R) // stride + 1, (wp - S) // stride + 1
+    if not want_out and emit is None:
+        raise ValueError("conv2d_i8_stem: nothing to produce (want_out=False without emit)")
+
+    def alloc(dtype):
+        return torch.empty((n, K_, P, Q), dtype=dtype, device=xpad.device, memory_format=torch.channels_last)
+    out = alloc(torch.float32) if want_out else None
+    w_scale = _f32c(w_scale.detach(), xpad).reshape(-1)
+    if w_scale.numel() == 1:
+        w_scale = w_scale.expand(K_).contiguous()
+    in_scale = _f32c(in_scale.detach(), xpad).reshape(-1)
+    in_zp = None if in_zp is None else _f32c(in_zp, xpad).reshape(-1)
+    bias = None if bias is None else bias.detach().contiguous()
+    out_codes = q_scale = q_zp = None
+    lo = hi = form = 0
+    g = 0.0
+    if emit is not None:
+        out_codes = alloc(emit.dtype)
+        q_scale = _f32c(emit.scale.detach(), xpad).reshape(-1)
+        q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, xpad).reshape(-1)
+        lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
+    oe = n * K_ * P * Q
+    PROFILE.launch("conv_stem", xpad.numel() + wq.numel() + oe * (4 * want_out + (emit is not None)),
+                   lambda: N.check(N.lib.dlmcq_conv2d_i8_stem_fused(
+                       N.ptr(xpad), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),
+                       n, hp, wp, K_, R, int(S), int(stride), int(xpad.dtype == torch.uint8), int(bool(relu)), N.ptr(out_codes),
+                       N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())))
+    return (out, out_codes) if emit is not None else out
+
+
+def maxpool_codes(codes, kernel, stride, padding):
+    """nn.MaxPool2d on channels_last activation codes (uint8 / int8), C % 4 == 0."""
+    N.require_gpu(codes)
+    n, c, h, w = codes.shape
+    if not codes.is_contiguous(memory_format=torch.channels_last):
+        codes = codes.contiguous(memory_format=torch.channels_last)
+    P, Q = (h + 2 * padding - kernel) // stride + 1, (w + 2 * padding - kernel) // stride + 1
+    y = torch.empty((n, c, P, Q), dtype=codes.dtype, device=codes.device, memory_format=torch.channels_last)
+    PROFILE.launch("pool_codes", codes.numel() + y.numel(), lambda: N.check(N.lib.dlmcq_maxpool_codes_nhwc(
+        N.ptr(codes), N.ptr(y), n, h, w, c, int(kernel), int(stride), int(padding), int(codes.dtype == torch.uint8),
+        N.stream_ptr())))
+    return y
+
+
 def pack_int4(codes):
     N.require_gpu(codes)
     codes = codes.contiguous().view(torch.int8)

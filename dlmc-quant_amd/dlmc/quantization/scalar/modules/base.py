@@ -22,7 +22,7 @@ from torch.nn import Module
 
 from .... import _native as N
 from .. import ops
-from .._wrapper import (InitState, fake_quant, int8_forward, int8_gemm_default, int8_layer_ok, set_scale,
+from .._wrapper import (InitState, fake_quant, int8_forward, int8_gemm_default, int8_kind, set_scale,
                         ste_scale_value)
 from ..utils import get_qrange
 
@@ -59,7 +59,7 @@ class QBase(Module):
         cfg = self.qconfig
         if not (self.int8_gemm and cfg["input"]["enable"] and cfg["weight"]["enable"]) or torch.is_grad_enabled():
             return False
-        if self.in_scale.numel() != 1 or self.wt_scale.numel() != 1 or not int8_layer_ok(self):
+        if self.in_scale.numel() != 1 or self.wt_scale.numel() != 1 or int8_kind(self) is None:
             return False
         if not (-128 <= self.in_min_val and self.in_max_val <= 127 and -128 <= self.wt_min_val and self.wt_max_val <= 127):
             return False

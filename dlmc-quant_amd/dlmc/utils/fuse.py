@@ -27,12 +27,12 @@ from torch import nn
 
 from .. import _native as N
 from ..quantization.scalar import kernels as K
-from ..quantization.scalar._wrapper import int8_layer_ok, ste_scale_value
+from ..quantization.scalar._wrapper import int8_kind, ste_scale_value
 from ..quantization.scalar.FSPTQuant.base import FSPTQBase
 from ..quantization.scalar.modules.base import QBase
 from ..quantization.scalar.RootQ.base import RootQBase
 
-__all__ = ["fuse_inference", "Int8Layer", "FusionReport"]
+__all__ = ["fuse_inference", "Int8Layer", "StemLayer", "FusionReport"]
 
 
 # ---------------------------------------------------------------------------------- frozen quantiser specs
@@ -56,9 +56,17 @@ def _byte_range(lo, hi):
 
 
 def _frozen_spec(mod):
-    """(_ActSpec, weight scale, weight lo, weight hi) if `mod` can run on the int8 kernel with frozen scales."""
+    """(_ActSpec, weight scale, weight lo, weight hi, kind) if `mod` can run on an int8 kernel with frozen scales;
+    kind "gemm" = conv_i8.hip (input channels % 64 == 0), "stem" = conv_stem_i8.hip (<= 4 input channels)."""
+    spec = _frozen_spec_(mod)
+    return None if spec is None else spec + (int8_kind(mod),)
+
+
+def _frozen_spec_(mod):
+    if int8_kind(mod) is None:
+        return None
     if isinstance(mod, FSPTQBase):
-        if not (mod.act_quant and mod.wt_quant) or mod.in_scale.numel() != 1 or not int8_layer_ok(mod):
+        if not (mod.act_quant and mod.wt_quant) or mod.in_scale.numel() != 1:
             return None
         if mod.qconfig["weight"].get("recon_type") in ("adaround", "dist_recon"):
             return None
@@ -75,7 +83,7 @@ def _frozen_spec(mod):
         return act, mod.wt_scale.detach().clone(), mod.wt_min_val, mod.wt_max_val
     if isinstance(mod, QBase):
         cfg = mod.qconfig
-        if not (cfg["input"]["enable"] and cfg["weight"]["enable"]) or not int8_layer_ok(mod):
+        if not (cfg["input"]["enable"] and cfg["weight"]["enable"]):
             return None
         if mod.in_scale.numel() != 1 or mod.wt_scale.numel() != 1:
             return None
@@ -93,20 +101,16 @@ def _frozen_spec(mod):
 
 
 # -------------------------------------------------------------------------------------------- plan nodes
-class Int8Layer(nn.Module):
-    """One quantised conv / linear of the frozen plan.  Input: the producer's codes (uint8/int8) or an fp32
-    tensor (quantised here, one pass).  Output: `(fp32 or None, consumer codes or None)`."""
+class _PlanLayer(nn.Module):
+    """Common part of the plan nodes: frozen quantiser constants, the consumer's emit spec, pooling on codes."""
 
-    def __init__(self, layer, spec, relu=False, emit=None, want_out=True):
+    def __init__(self, layer, spec, relu=False, emit=None, want_out=True, pool=None):
         super().__init__()
         self.layer = layer
-        self.act, w_scale, w_lo, w_hi = spec
-        self.relu, self.emit, self.want_out = bool(relu), emit, bool(want_out)
-        wq, wsum = K.quantize_weight_krsc(layer.weight, w_scale, w_lo, w_hi)
+        self.act, w_scale, self.w_lo, self.w_hi, self.kind = spec
+        self.relu, self.emit, self.want_out, self.pool = bool(relu), emit, bool(want_out), pool
         k = layer.weight.shape[0]
         w_scale = w_scale.detach().to(torch.float32).reshape(-1)
-        self.register_buffer("wq", wq, persistent=False)
-        self.register_buffer("wsum", wsum, persistent=False)
         self.register_buffer("w_scale", (w_scale.expand(k) if w_scale.numel() == 1 else w_scale).contiguous(),
                              persistent=False)
         self._deq = {}     # QBase dequantises with s^ = grad_scale(s, g(numel)): one tiny tensor per input size
@@ -118,6 +122,31 @@ class Int8Layer(nn.Module):
         if s is None:
             s = self._deq[numel] = ste_scale_value(self.act.scale, self.act.g(numel)).contiguous()
         return s
+
+    def _emit_for(self, n, k, p, q):
+        """The consumer's quantiser; its g (QBase) is taken over ITS input = this node's (pooled) output."""
+        if self.emit is None:
+            return None
+        if self.pool is not None:
+            kk, ss, pp = self.pool
+            p, q = (p + 2 * pp - kk) // ss + 1, (q + 2 * pp - kk) // ss + 1
+        return self.emit.emit(n * k * p * q)
+
+    def _finish(self, out, codes):
+        if self.pool is not None:
+            codes = K.maxpool_codes(codes, *self.pool)
+        return out, codes
+
+
+class Int8Layer(_PlanLayer):
+    """One quantised conv / linear of the frozen plan (input channels % 64 == 0).  Input: the producer's codes
+    (uint8/int8) or an fp32 tensor (quantised here, one pass).  Output: `(fp32 or None, consumer codes or None)`."""
+
+    def __init__(self, layer, spec, **kw):
+        super().__init__(layer, spec, **kw)
+        wq, wsum = K.quantize_weight_krsc(layer.weight, self.w_scale, self.w_lo, self.w_hi)
+        self.register_buffer("wq", wq, persistent=False)
+        self.register_buffer("wsum", wsum, persistent=False)
 
     def forward(self, x, residual=None):
         lay, act = self.layer, self.act
@@ -136,21 +165,16 @@ class Int8Layer(nn.Module):
             if x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
                 x = x.contiguous(memory_format=torch.channels_last)
             _, codes = K.fake_quant(x, act.scale, act.zp, act.lo, act.hi, act.form, g=act.g(numel), codes="i8", want_y=False)
-        kw = {} if linear else dict(stride=lay.stride[0], padding=lay.padding[0], dilation=lay.dilation[0])
-        if self.relu or residual is not None or self.emit is not None:
-            emit = None
-            if self.emit is not None:
-                k = lay.weight.shape[0]
-                out_numel = None
-                if self.emit.needs_g:      # the consumer's g uses ITS input size = this layer's output size
-                    if linear:
-                        out_numel = codes.shape[0] * k
-                    else:
-                        r, s = lay.weight.shape[2], lay.weight.shape[3]
-                        p = (codes.shape[2] + 2 * lay.padding[0] - lay.dilation[0] * (r - 1) - 1) // lay.stride[0] + 1
-                        q = (codes.shape[3] + 2 * lay.padding[0] - lay.dilation[0] * (s - 1) - 1) // lay.stride[0] + 1
-                        out_numel = codes.shape[0] * k * p * q
-                emit = self.emit.emit(out_numel)
+        k = lay.weight.shape[0]
+        if linear:
+            kw, emit = {}, self._emit_for(codes.shape[0], k, 1, 1)
+        else:
+            st, pd, dl = lay.stride[0], lay.padding[0], lay.dilation[0]
+            kw = dict(stride=st, padding=pd, dilation=dl)
+            r, s = lay.weight.shape[2], lay.weight.shape[3]
+            emit = self._emit_for(codes.shape[0], k, (codes.shape[2] + 2 * pd - dl * (r - 1) - 1) // st + 1,
+                                  (codes.shape[3] + 2 * pd - dl * (s - 1) - 1) // st + 1)
+        if self.relu or residual is not None or emit is not None:
             res = K.conv2d_i8(codes, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale,
                               residual=residual, relu=self.relu, emit=emit, want_out=self.want_out, **kw)
             out, out_codes = res if emit is not None else (res, None)
@@ -159,19 +183,43 @@ class Int8Layer(nn.Module):
         if lead is not None:
             out = None if out is None else out.reshape(*lead, out.shape[-1])
             out_codes = None if out_codes is None else out_codes.reshape(*lead, out_codes.shape[-1])
-        return out, out_codes
+        return self._finish(out, out_codes)
+
+
+class StemLayer(_PlanLayer):
+    """The network's first convolution (<= 4 input channels) of the frozen plan: the image is quantised into a
+    zero-point-padded NHWC4 code buffer and convolved on the matrix cores (csrc/conv_stem_i8.hip)."""
+
+    def __init__(self, layer, spec, **kw):
+        super().__init__(layer, spec, **kw)
+        wq, wsum = K.quantize_weight_stem(layer.weight, self.w_scale, self.w_lo, self.w_hi)
+        self.register_buffer("wq", wq, persistent=False)
+        self.register_buffer("wsum", wsum, persistent=False)
+
+    def forward(self, x):
+        lay, act = self.layer, self.act
+        numel = x.numel()
+        pad, st = lay.padding[0], lay.stride[0]
+        xpad = K.quantize_pad_nhwc4(x, act.scale, act.zp, act.lo, act.hi, act.form, pad, g=act.g(numel))
+        k, _, r, s = lay.weight.shape
+        emit = self._emit_for(x.shape[0], k, (x.shape[2] + 2 * pad - r) // st + 1, (x.shape[3] + 2 * pad - s) // st + 1)
+        res = K.conv2d_i8_stem(xpad, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale, s, stride=st,
+                               relu=self.relu, emit=emit, want_out=self.want_out)
+        out, out_codes = res if emit is not None else (res, None)
+        return self._finish(out, out_codes)
 
 
 class FusionReport:
     """What the pass did, for logs and tests."""
 
     def __init__(self):
-        self.layers = self.relu = self.residual = self.emit = self.fp32_outputs = 0
+        self.layers = self.relu = self.residual = self.emit = self.fp32_outputs = self.stem = self.pooled = 0
         self.skipped = []
 
     def __repr__(self):
         return (f"FusionReport(int8 layers={self.layers}, relu fused={self.relu}, residual fused={self.residual}, "
-                f"code-emitting={self.emit}, fp32 outputs kept={self.fp32_outputs}, not eligible={self.skipped})")
+                f"code-emitting={self.emit}, fp32 outputs kept={self.fp32_outputs}, stem layers={self.stem}, "
+                f"pools on codes={self.pooled}, not eligible={self.skipped})")
 
 
 class _Tracer(fx.Tracer):
@@ -199,6 +247,18 @@ def _is_relu(node, modules):
     if node.op == "call_function":
         return node.target in _RELU_FNS
     return node.op == "call_method" and node.target in ("relu", "relu_")
+
+
+def _pool_params(node, modules):
+    """(kernel, stride, padding) if `node` is an nn.MaxPool2d the code-domain pool reproduces."""
+    if node.op != "call_module" or type(modules.get(node.target)) is not nn.MaxPool2d:
+        return None
+    m = modules[node.target]
+    one = lambda v: v[0] if isinstance(v, (tuple, list)) and len(set(v)) == 1 else (v if isinstance(v, int) else None)  # noqa: E731
+    k, s, p, d = one(m.kernel_size), one(m.stride if m.stride is not None else m.kernel_size), one(m.padding), one(m.dilation)
+    if None in (k, s, p, d) or d != 1 or m.ceil_mode or m.return_indices:
+        return None
+    return k, s, p
 
 
 def fuse_inference(model, report=None):
@@ -237,7 +297,7 @@ def fuse_inference(model, report=None):
         # ---- the chain  layer -> (+ shortcut) -> ReLU, each link the sole user of the previous one ----
         chain, last, residual, relu = [node], node, None, False
         users = list(last.users)
-        if len(users) == 1 and _is_add(users[0]) and users[0].args[0] is not users[0].args[1]:
+        if spec[4] == "gemm" and len(users) == 1 and _is_add(users[0]) and users[0].args[0] is not users[0].args[1]:   # (the stem kernel has no shortcut input)
             add = users[0]
             residual = add.args[1] if add.args[0] is last else add.args[0]
             chain.append(add)
@@ -247,12 +307,22 @@ def fuse_inference(model, report=None):
             relu = True
             chain.append(users[0])
             last = users[0]
+            users = list(last.users)
+        # ---- a max-pool read only by int8 layers of one quantiser runs on the codes (monotone quantiser) ----
+        pool = None
+        if len(users) == 1 and _pool_params(users[0], modules) is not None and modules[node.target].weight.shape[0] % 4 == 0:
+            mp = users[0]
+            cons = [spec_of(u) if u.args and u.args[0] is mp else None for u in mp.users]
+            if cons and all(c is not None and c[4] == "gemm" for c in cons) and len({c[0].key for c in cons}) == 1:
+                pool = _pool_params(mp, modules)
+                chain.append(mp)
+                last = mp
         # ---- who reads the result: int8 layers fed ONLY through their activation argument take codes ----
         consumers = {}
         fp32_needed = False
         for u in last.users:
             s = spec_of(u) if u.args and u.args[0] is last else None
-            if s is None:
+            if s is None or s[4] != "gemm":
                 fp32_needed = True
             else:
                 consumers.setdefault(s[0].key, []).append((u, s[0]))
@@ -268,7 +338,8 @@ def fuse_inference(model, report=None):
         count += 1
         specs[name] = None
         modules[name] = None
-        gm.add_module(name, Int8Layer(modules[node.target], spec, relu=relu, emit=emit, want_out=fp32_needed or emit is None))
+        cls = Int8Layer if spec[4] == "gemm" else StemLayer
+        gm.add_module(name, cls(modules[node.target], spec, relu=relu, emit=emit, want_out=fp32_needed or emit is None, pool=pool))
         with graph.inserting_after(last):
             fused = graph.call_module(name, args=(node.args[0],) if residual is None else (node.args[0], residual))
         with graph.inserting_after(fused):
@@ -281,6 +352,8 @@ def fuse_inference(model, report=None):
         for n in reversed(chain):
             graph.erase_node(n)
         report.layers += 1
+        report.stem += spec[4] == "stem"
+        report.pooled += pool is not None
         report.relu += relu
         report.residual += residual is not None
         report.emit += emit is not None

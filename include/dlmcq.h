@@ -279,6 +279,44 @@ int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float* out, const
                                const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
                                int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
 
+/* ---- the 3-channel first layer and its max-pool, in the integer-code domain (csrc/conv_stem_i8.hip) ---- */
+
+/*
+ * Quantise an image batch (C <= 4 channels, any memory format: element strides given) to activation codes in a
+ * zero-point-PADDED NHWC buffer with 4 bytes per pixel: out[N][H+2*pad][W+2*pad][4], border = the code of
+ * x' = 0 (zero padding of the fake-quantised image, modules/conv.py:18-19), bytes c >= C unspecified.
+ * Forms EMULATE / QBASE / ZEROPOINT / SYMMETRIC as in dlmcq_fake_quant_f32 (same arithmetic, same codes).
+ * The consumer over-reads up to 32 bytes past the last pixel: allocate N*(H+2*pad)*(W+2*pad)*4 + 32 bytes.
+ */
+int dlmcq_quantize_pad_nhwc4(const float* x, void* out, const float* scale, const float* zero_point, int64_t N,
+                             int64_t C, int64_t H, int64_t W, int64_t stride_n, int64_t stride_c, int64_t stride_h,
+                             int64_t stride_w, int32_t pad, int32_t lo, int32_t hi, int32_t form, float ste_g,
+                             dlmcq_stream_t stream);
+
+/* Weights fp32 KCRS (C <= 4, R <= 7, S <= 8) -> int8 [K][R][8][4] zero-filled, SYMMETRIC form, + wsum[K]. */
+int dlmcq_quantize_weight_stem_i8(const float* w, int8_t* wq, int32_t* wsum, const float* scale, int64_t K,
+                                  int64_t C, int64_t R, int64_t S, int32_t lo, int32_t hi, dlmcq_stream_t stream);
+
+/*
+ * The convolution of modules/conv.py:18-19 for such a layer: out[n,p,q,k] = in_scale*w_scale[k]*SUM (x - zp)*wq
+ * + bias[k] over the padded codes (P = (Hp - R)/stride + 1, Q = (Wp - S)/stride + 1, dilation 1), then the
+ * epilogue of dlmcq_conv2d_i8_nhwc_fused (ReLU, fp32 NHWC output and / or the consumer's codes).  K % 4 == 0.
+ */
+int dlmcq_conv2d_i8_stem_fused(const void* xpad, const int8_t* w, float* out, const float* bias,
+                               const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                               const float* w_scale, int64_t N, int64_t Hp, int64_t Wp, int64_t K, int64_t R,
+                               int64_t S, int32_t stride, int32_t x_is_unsigned, int32_t relu, void* codes,
+                               const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
+                               int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
+
+/*
+ * nn.MaxPool2d (square window, dilation 1, floor mode) on NHWC activation codes.  The quantisers of this library
+ * are monotone, so  code(maxpool(v)) == maxpool(code(v)):  pooling the 1-byte codes replaces pooling the fp32
+ * tensor and quantising the result.  C % 4 == 0; padding never wins (torch pads with -inf).
+ */
+int dlmcq_maxpool_codes_nhwc(const void* x, void* y, int64_t N, int64_t H, int64_t W, int64_t C, int32_t kernel,
+                             int32_t stride, int32_t pad, int32_t x_is_unsigned, dlmcq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

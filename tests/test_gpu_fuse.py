@@ -101,10 +101,13 @@ QBASE = {"weight": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 
          "exclude_layers": [], "override_options": []}
 
 
-@pytest.mark.parametrize("arch,qtype,cfg,res", [("resnet50", "FSPTQ", FSPTQ, 64), ("resnet18", "FSPTQ", FSPTQ, 96),
-                                                ("repvgg_a1", "FSPTQ", FSPTQ, 64), ("resnet18", None, QBASE, 64),
-                                                ("mobileone_s1", "FSPTQ", FSPTQ, 64)])
-def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res):
+@pytest.mark.parametrize("arch,qtype,cfg,res,signed_image", [
+    ("resnet50", "FSPTQ", FSPTQ, 64, False), ("resnet18", "FSPTQ", FSPTQ, 96, True), ("repvgg_a1", "FSPTQ", FSPTQ, 64, False),
+    ("resnet18", None, QBASE, 64, True), ("mobileone_s1", "FSPTQ", FSPTQ, 64, False)])
+def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res, signed_image):
+    """`signed_image`: N(0,1) pixels.  Under the FSPTQ u8 activation config the reference's zero point is then the
+    (negative, non-integer) minimum (FSPTQuant/base.py:99-103 via ops.py:20-34), the first layer's codes are not
+    integers and it keeps its fp32 path; with non-negative pixels (min = 0) it runs on the stem kernel."""
     import workloads as W
     from dlmc.utils.fuse import fuse_inference
     from dlmc.utils.merge_bn import merge_bn
@@ -118,6 +121,8 @@ def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res):
     net = merge_bn(net, inplace=True)
     quantize_model(net, cfg, None, qtype, int8_gemm=True)
     x = torch.randn(4, 3, res, res, device=DEV)
+    if not signed_image:
+        x = torch.relu(x)
     with torch.no_grad():
         net(x)                                    # calibrate
         want = net(x * 0.8)
@@ -128,14 +133,102 @@ def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res):
         got = fused(x * 0.8)
     same(got, want, f"{arch} {qtype} logits")
     if arch == "resnet50":
-        assert rep.layers == 53 and rep.residual == 16 and rep.relu == 48 and rep.skipped == ["conv1"]
-        assert rep.emit == 47 and rep.fp32_outputs == 18   # 12 shortcuts + 4 residual feeds + last block + fc
+        assert rep.layers == 54 and rep.residual == 16 and rep.relu == 49 and rep.skipped == []
+        assert rep.stem == 1 and rep.pooled == 1           # conv1 -> ReLU -> max-pool, pooled as codes
+        assert rep.emit == 48 and rep.fp32_outputs == 18   # 12 shortcuts + 4 residual feeds + last block + fc
     if arch == "repvgg_a1":
-        assert rep.layers == 22 and rep.relu == 21 and rep.fp32_outputs == 2    # the last block (feeds the pool) and the classifier
+        assert rep.layers == 23 and rep.relu == 22 and rep.stem == 1 and rep.skipped == []
+    if arch == "resnet18" and qtype == "FSPTQ":
+        assert rep.stem == 0 and rep.skipped == ["conv1"]       # non-integer zero point: fp32 first layer
+    if arch == "resnet18" and qtype is None:
+        assert rep.stem == 1 and rep.pooled == 1                # QBase: symmetric signed codes, zero offset
+        assert rep.fp32_outputs == 2    # the last block (feeds the pool) and the classifier
     # and under a HIP graph
     from dlmc.utils.graph import GraphedForward
     fwd = GraphedForward(fused, x)
     same(fwd(x * 0.8), want, f"{arch} {qtype} graphed")
+
+
+STEM_CASES = [  # N, C, H, W, K, R, S, stride, pad
+    (2, 3, 32, 32, 64, 7, 7, 2, 3),      # ResNet
+    (3, 3, 17, 23, 64, 3, 3, 2, 1),      # RepVGG / MobileOne stage0, odd sizes
+    (2, 3, 16, 16, 96, 3, 3, 1, 1),      # two 64-channel slabs, the second half empty
+    (1, 4, 12, 12, 32, 5, 5, 1, 2),
+    (2, 1, 9, 9, 8, 1, 1, 1, 0),
+    (9, 3, 20, 20, 64, 7, 8, 2, 3),      # 8 taps per row; M = 9*10*9 = 810 (ragged tile)
+]
+
+
+@pytest.mark.parametrize("unsigned", [True, False])
+def test_stem_kernels_match_the_generic_path(unsigned):
+    """quantize_pad_nhwc4 + conv2d_i8_stem against fake_quant codes and a float64 convolution of the dequantised
+    operands; every epilogue option against the separate kernels, bit for bit."""
+    import torch.nn.functional as F
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    lo, hi = (0, 255) if unsigned else (-127, 127)
+    for idx, (n, c, h, w, k, r, s, stride, pad) in enumerate(STEM_CASES):
+        gg = gen(100 + idx)
+        x = torch.randn(n, c, h, w, generator=gg).to(DEV)
+        if idx % 2:
+            x = x.contiguous(memory_format=torch.channels_last)
+        s_in = torch.tensor([float(x.abs().max()) / (127 if not unsigned else 200)], device=DEV)
+        zp = torch.tensor([117.0 if unsigned else 0.0], device=DEV)
+        form = N.FORM_ZEROPOINT
+        _, want_codes = K.fake_quant(x, s_in, zp, lo, hi, form, codes="i8", want_y=False)
+        xpad = K.quantize_pad_nhwc4(x, s_in, zp, lo, hi, form, pad)
+        assert xpad.shape == (n, h + 2 * pad, w + 2 * pad, 4)
+        inner = xpad[:, pad:pad + h, pad:pad + w, :c].permute(0, 3, 1, 2)
+        same(inner.contiguous(), want_codes.contiguous(), f"stem case {idx} image codes")
+        if pad:
+            border = torch.cat([xpad[:, :pad, :, :c].reshape(-1), xpad[:, :, :pad, :c].reshape(-1), xpad[:, -pad:, :, :c].reshape(-1),
+                                xpad[:, :, -pad:, :c].reshape(-1)])
+            assert bool((border.to(torch.float32) == float(zp)).all()), f"stem case {idx} border"
+        wt = (torch.randn(k, c, r, s, generator=gg) * 0.1).to(DEV)
+        s_w = wt.abs().amax(dim=(1, 2, 3)) / 127 + 1e-6
+        bias = torch.randn(k, generator=gg).to(DEV)
+        wq, wsum = K.quantize_weight_stem(wt, s_w, -127, 127)
+        qw = torch.clamp(torch.round(wt.cpu() / s_w.cpu().reshape(-1, 1, 1, 1)), -127, 127)
+        assert torch.equal(wq[:, :, :s, :c].cpu().to(torch.float32), qw.permute(0, 2, 3, 1)), f"stem case {idx} wq"
+        assert int(wq[:, :, s:, :].abs().sum()) == 0 and int(wq[:, :, :, c:].abs().sum()) == 0
+        assert torch.equal(wsum.cpu().double(), qw.double().sum(dim=(1, 2, 3)))
+        plain = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=stride)
+        ref = F.conv2d((want_codes.cpu().double() - float(zp)) * float(s_in), qw.double() * s_w.cpu().double().reshape(-1, 1, 1, 1),
+                       bias.cpu().double(), stride=stride, padding=pad)
+        assert plain.shape == ref.shape and plain.is_contiguous(memory_format=torch.channels_last)
+        torch.testing.assert_close(plain.cpu().double(), ref, rtol=2e-6, atol=2e-5, msg=lambda m: f"stem case {idx}: {m}")
+        q_s = torch.tensor([float(plain.abs().max()) / 255 * 0.8], device=DEV)
+        emit = K.EmitCodes(q_s, torch.tensor([0.0], device=DEV), 0, 255, N.FORM_ZEROPOINT)
+        want = torch.relu(plain)
+        _, wc = K.fake_quant(want, q_s, emit.zero_point, 0, 255, N.FORM_ZEROPOINT, codes="i8", want_y=False)
+        out, codes = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=stride, relu=True, emit=emit)
+        same(out, want, f"stem case {idx} relu out")
+        same(codes, wc, f"stem case {idx} codes")
+        none, codes2 = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=stride, relu=True, emit=emit, want_out=False)
+        assert none is None
+        same(codes2, wc, f"stem case {idx} codes-only")
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.int8])
+def test_maxpool_on_codes_equals_quantised_maxpool(dtype):
+    import torch.nn.functional as F
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    for idx, (n, c, h, w, k, s, p) in enumerate([(2, 64, 16, 16, 3, 2, 1), (3, 8, 9, 11, 2, 2, 0), (1, 128, 7, 7, 3, 1, 1),
+                                                 (2, 4, 5, 6, 3, 3, 1)]):
+        gg = gen(200 + idx)
+        lo, hi = (0, 256) if dtype == torch.uint8 else (-128, 128)
+        codes = torch.randint(lo, hi, (n, c, h, w), generator=gg).to(dtype).to(DEV).contiguous(memory_format=torch.channels_last)
+        got = K.maxpool_codes(codes, k, s, p)
+        want = F.max_pool2d(codes.float(), k, s, p).to(dtype)
+        same(got, want.contiguous(memory_format=torch.channels_last), f"pool case {idx}")
+    # and the commutation itself: quantise(maxpool(v)) == maxpool(quantise(v))
+    v = torch.randn(2, 64, 14, 14, generator=gen(300)).to(DEV).contiguous(memory_format=torch.channels_last)
+    s_q, zp = torch.tensor([0.011], device=DEV), torch.tensor([3.0 if dtype == torch.uint8 else -2.0], device=DEV)
+    lo, hi = (0, 255) if dtype == torch.uint8 else (-127, 127)
+    _, a = K.fake_quant(F.max_pool2d(v, 3, 2, 1), s_q, zp, lo, hi, N.FORM_ZEROPOINT, codes="i8", want_y=False)
+    _, b = K.fake_quant(v, s_q, zp, lo, hi, N.FORM_ZEROPOINT, codes="i8", want_y=False)
+    same(K.maxpool_codes(b, 3, 2, 1), a, "commutation")
 
 
 def test_fuse_requires_a_calibrated_eval_model():

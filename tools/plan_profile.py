@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the fused plan (HIP events around every plan node).  python tools/plan_profile.py [model] [batch]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dlmc-quant_amd")]
+import torch  # noqa: E402
+
+import workloads as W  # noqa: E402
+from bench import QCFG  # noqa: E402
+from dlmc.utils.fuse import Int8Layer, fuse_inference  # noqa: E402
+from dlmc.utils.merge_bn import merge_bn  # noqa: E402
+from dlmc.utils.quantize import quantize_model  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+dev = "cuda:0"
+torch.manual_seed(2333)
+model = merge_bn(W.MODELS[name]().to(dev).eval(), inplace=True, allow_missing=True)
+quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=True)
+x = torch.randn(batch, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+recs = []
+with torch.no_grad():
+    model(x)
+    plan = fuse_inference(model)
+    for _ in range(2):
+        plan(x)
+
+    def pre(mod, args):
+        mod._ev = torch.cuda.Event(enable_timing=True)
+        mod._ev.record()
+
+    def post(mod, args, out):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        recs.append((mod, args, out, mod._ev, e))
+    for m in plan.modules():
+        if isinstance(m, Int8Layer):
+            m.register_forward_pre_hook(pre)
+            m.register_forward_hook(post)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    plan(x)
+    b.record()
+    torch.cuda.synchronize()
+print(f"whole forward {a.elapsed_time(b):.2f} ms")
+tot = 0.0
+for mod, args, out, s, e in recs:
+    lay = mod.layer
+    us = s.elapsed_time(e) * 1e3
+    tot += us
+    xin = args[0]
+    o = out[0] if out[0] is not None else out[1]
+    w = lay.weight
+    macs = o.numel() * (w.numel() // w.shape[0])
+    nbytes = xin.numel() * (1 if xin.dtype != torch.float32 else 5) + w.numel() + o.numel() * (
+        4 * (out[0] is not None) + (out[1] is not None) + 4 * (len(args) > 1))
+    print(f"{us:8.1f} us  in {str(tuple(xin.shape)):22s} {str(xin.dtype)[6:]:8s} w {str(tuple(w.shape)):20s} "
+          f"{'res ' if len(args) > 1 else '    '}{'relu ' if mod.relu else '     '}{'out ' if out[0] is not None else '    '}"
+          f"{'codes' if out[1] is not None else '     '}  {2 * macs / us / 1e6:6.0f} TOP/s {nbytes / us / 1e3:6.0f} GB/s")
+print(f"plan nodes {tot / 1e3:.2f} ms")
