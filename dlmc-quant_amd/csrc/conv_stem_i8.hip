@@ -40,7 +40,7 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void quantize_pad_nhwc4_kernel(const f
     const float q = clamp_nan(__builtin_rintf((v - of) / dv) + zadd, lo, hi);
     return (uint32_t)(code_of(q) & 0xff);
   };
-  const uint32_t border = code(0.0f) * 0x00010101u;   // x' = 0 (zero padding of the fake-quantised image)
+  const uint32_t border = code(0.0f) * 0x01010101u;   // x' = 0 (zero padding of the fake-quantised image) in every channel
   const int64_t total = (int64_t)g.N * g.Hp * g.Wp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t t = fdiv((uint32_t)i, g.wdiv);

@@ -138,11 +138,11 @@ def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res, sign
         assert rep.emit == 48 and rep.fp32_outputs == 18   # 12 shortcuts + 4 residual feeds + last block + fc
     if arch == "repvgg_a1":
         assert rep.layers == 23 and rep.relu == 22 and rep.stem == 1 and rep.skipped == []
+        assert rep.fp32_outputs == 2    # the last block (feeds the pool) and the classifier
     if arch == "resnet18" and qtype == "FSPTQ":
         assert rep.stem == 0 and rep.skipped == ["conv1"]       # non-integer zero point: fp32 first layer
     if arch == "resnet18" and qtype is None:
-        assert rep.stem == 1 and rep.pooled == 1                # QBase: symmetric signed codes, zero offset
-        assert rep.fp32_outputs == 2    # the last block (feeds the pool) and the classifier
+        assert rep.stem == 1 and rep.pooled == 0                # QBase: signed codes, zero offset; this pool also feeds a shortcut
     # and under a HIP graph
     from dlmc.utils.graph import GraphedForward
     fwd = GraphedForward(fused, x)
