@@ -209,14 +209,28 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // ABL (timing-only ablations, never shipped): 1 = no operand DMA inside the K loop, 2 = no MFMA, 4 = no LDS fragment reads
-template <int BM, int BN, int NBUF = 3, int BK = CV_BK, int ABL = 0>
-__global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+// A second (input, weight) pair accumulated into the same output tile - the shortcut convolution of a residual
+// block's first unit, so that  conv3(x) + downsample(y)  is one kernel and neither addend travels through HBM.
+struct ConvSeg2 {
+  const int8_t* x;
+  const int8_t* w;
+  const float* bias;
+  const int32_t* wsum;
+  const float* s_in;
+  const float* zp_in;
+  const float* s_w;
+  ConvGeom g;
+  int shift;
+};
+
+template <int BM, int BN, int NBUF = 3, int BK = CV_BK, int ABL = 0, bool DUAL = false>
+__global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                          float* __restrict__ out, const float* __restrict__ bias,
                                                          const int32_t* __restrict__ wsum,
                                                          const float* __restrict__ s_in,
                                                          const float* __restrict__ zp_in,
                                                          const float* __restrict__ s_w, ConvGeom g, int shift,
-                                                         ConvEpi ep) {
+                                                         ConvEpi ep, ConvSeg2 sg) {
   constexpr int PF = NBUF - 1;  // K steps in flight
   constexpr int TILE_A = BM * BK, TILE_B = BN * BK, TILE = TILE_A + TILE_B;
   constexpr int MT = BM / 128;  // 32-row slabs per wave along M (a wave owns BM/4 consecutive rows)
@@ -237,8 +251,12 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_i8_dma_kernel(c
   const int n0 = bn * BN;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const float zpf = zp_in ? zp_in[0] : 0.0f;
-  const int zpi = (int)__builtin_rintf(zpf);
+  const int wrow0 = wave * (BM / 4);            // first tile row of this wave
+  const int hsel = lane >> 5;
+  i32x16 acc[MT][NT];
+
+  // One (input, weight) pair: the whole pipelined reduction into acc.  Called once, or twice when DUAL.
+  auto reduce = [&](const int8_t* __restrict__ x, const int8_t* __restrict__ w, const ConvGeom& g, int zpi, int shift) {
   const int8_t* padline = g_pad_table.b + ((zpi & 0xff) << 4);   // stored UNshifted: the xor happens on read
   const uint32_t xorw = shift ? 0x80808080u : 0u;
 
@@ -294,7 +312,6 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_i8_dma_kernel(c
     if (++f_buf == NBUF) f_buf = 0;
   };
 
-  i32x16 acc[MT][NT];
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -302,8 +319,6 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_i8_dma_kernel(c
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mi][j][i] = 0;
 
-  const int wrow0 = wave * (BM / 4);            // first tile row of this wave
-  const int hsel = lane >> 5;
 #pragma unroll
   for (int i = 0; i < PF; ++i)
     if (i < nsteps) issue();
@@ -357,6 +372,32 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_i8_dma_kernel(c
     }
     if (++c_buf == NBUF) c_buf = 0;
   }
+  };   // reduce
+
+  // the shortcut pair first: its dequantised sum waits in registers while the main pair reduces
+  float extra[DUAL ? MT : 1][DUAL ? NT : 1][16];
+  if (DUAL) {
+    const float zf2 = sg.zp_in ? sg.zp_in[0] : 0.0f;
+    const int zpi2 = (int)__builtin_rintf(zf2);
+    reduce(sg.x, sg.w, sg.g, zpi2, sg.shift);
+    const float sin2 = sg.s_in[0];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + j * 32 + (lane & 31);
+      const bool cok = col < g.K;
+      const float mult = cok ? sin2 * sg.s_w[col] : 0.0f;
+      const int corr = cok ? (sg.shift - zpi2) * sg.wsum[col] : 0;
+      const float bv = (cok && sg.bias) ? sg.bias[col] : 0.0f;
+#pragma unroll
+      for (int mi = 0; mi < (DUAL ? MT : 1); ++mi)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) extra[mi][DUAL ? j : 0][i] = (float)(acc[mi][j][i] + corr) * mult + bv;
+    }
+    __builtin_amdgcn_s_barrier();   // every wave has left the ring before the main pair refills it
+  }
+  const float zpf = zp_in ? zp_in[0] : 0.0f;
+  const int zpi = (int)__builtin_rintf(zpf);
+  reduce(x, w, g, zpi, shift);
 
   const float sin = s_in[0];
   const EpiQuant eq(ep);
@@ -394,7 +435,9 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_i8_dma_kernel(c
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-          stg[r * EP_LD + jj * 32 + (lane & 31)] = (float)(acc[0][j][i] + corr) * mult + bv;
+          float v = (float)(acc[0][j][i] + corr) * mult + bv;
+          if (DUAL) v = v + extra[0][DUAL ? j : 0][i];
+          stg[r * EP_LD + jj * 32 + (lane & 31)] = v;
         }
       }
       // a wave only reads back what it wrote itself: no block barrier, just the LDS counter
@@ -433,6 +476,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_i8_dma_kernel(c
         if (row >= g.M) continue;
         const int64_t at = row * g.K + col;
         float v = (float)(acc[mi][j][i] + corr) * mult + bv;
+        if (DUAL) v = v + extra[DUAL ? mi : 0][DUAL ? j : 0][i];
         if (ep.residual) v = v + ep.residual[at];
         if (ep.relu) v = relu_nan(v);
         if (out) __builtin_nontemporal_store(v, out + at);
@@ -835,8 +879,8 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
                        const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N, int64_t H,
                        int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
                        int32_t dilation, int32_t x_is_unsigned, dlmcq_stream_t stream, int variant,
-                       const ConvEpi& ep = ConvEpi{}) {
-  const bool fused = ep.residual || ep.codes || ep.relu;
+                       const ConvEpi& ep = ConvEpi{}, const ConvSeg2* seg2 = nullptr) {
+  const bool fused = ep.residual || ep.codes || ep.relu || seg2;
   if (fused && !(variant == 1 || variant == 2 || variant == 3)) return DLMCQ_EINVAL;   // only the LDS-DMA kernel fuses
   if (N < 0 || H < 1 || W < 1 || C < 1 || K < 1 || R < 1 || S < 1 || stride < 1 || pad < 0 || dilation < 1)
     return DLMCQ_EINVAL;
@@ -862,7 +906,8 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   const int shift = x_is_unsigned ? 128 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int8_t* xs = reinterpret_cast<const int8_t*>(x);
-  const int bnn = (K <= 64 || (K % 128) != 0) ? 64 : 128;
+  static const int bn_force = [] { const char* e = getenv("DLMCQ_CONV_BN"); return e ? atoi(e) : 0; }();   // A/B measurements only
+  const int bnn = bn_force == 64 ? 64 : ((K <= 64 || (K % 128) != 0) ? 64 : 128);
   // 256-row tiles halve the weight-operand traffic per MAC; they pay off when the reduction is long (3x3 taps or
   // many input channels) and there are enough row tiles to fill the chip.  DLMCQ_CONV_VARIANT=2 forces 128 rows.
   const int64_t ksteps = R * S * (C / CV_BK);
@@ -894,12 +939,19 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   } else if (variant == 0) {
     if (bnn == 64) hipLaunchKernelGGL((conv_i8_kernel<64>), DLMCQ_CONV_ARGS);
     else hipLaunchKernelGGL((conv_i8_kernel<128>), DLMCQ_CONV_ARGS);
+  } else if (seg2) {
+    ConvSeg2 s2 = *seg2;
+    s2.g.nblk_m = g.nblk_m;
+    s2.g.nblk_n = g.nblk_n;
+    if (s2.g.M != g.M || s2.g.K != g.K || s2.g.P != g.P || s2.g.Q != g.Q || bmm != 128) return DLMCQ_EINVAL;
+    if (bnn == 64) hipLaunchKernelGGL((conv_i8_dma_kernel<128, 64, 3, CV_BK, 0, true>), DLMCQ_CONV_ARGS, ep, s2);
+    else hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 0, true>), DLMCQ_CONV_ARGS, ep, s2);
   } else if (bmm == 256) {
-    hipLaunchKernelGGL((conv_i8_dma_kernel<256, 128>), DLMCQ_CONV_ARGS, ep);
+    hipLaunchKernelGGL((conv_i8_dma_kernel<256, 128>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
   } else if (bnn == 64) {
-    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 64>), DLMCQ_CONV_ARGS, ep);
+    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 64>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
   } else {
-    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128>), DLMCQ_CONV_ARGS, ep);
+    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
   }
 #undef DLMCQ_CONV_ARGS
 #undef DLMCQ_CONV_ARGS_WS
@@ -935,6 +987,52 @@ extern "C" int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float*
   const int v = conv_variant();
   return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
                      x_is_unsigned, stream, (v >= 1 && v <= 3) ? v : 1, ep);
+}
+
+extern "C" int dlmcq_conv2d_i8_nhwc_dual(const void* x, const int8_t* w, float* out, const float* bias,
+                                         const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                                         const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
+                                         int64_t R, int64_t S, int32_t stride, int32_t pad, int32_t dilation,
+                                         int32_t x_is_unsigned, const void* x2, const int8_t* w2, const float* bias2,
+                                         const int32_t* wsum2, const float* in_scale2, const float* in_zero_point2,
+                                         const float* w_scale2, int64_t H2, int64_t W2, int64_t C2, int64_t R2,
+                                         int64_t S2, int32_t stride2, int32_t pad2, int32_t dilation2,
+                                         int32_t x2_is_unsigned, int32_t relu, void* codes, const float* q_scale,
+                                         const float* q_zero_point, int32_t q_lo, int32_t q_hi, int32_t q_form,
+                                         float q_ste_g, dlmcq_stream_t stream) {
+  if (H2 < 1 || W2 < 1 || C2 < 1 || R2 < 1 || S2 < 1 || stride2 < 1 || pad2 < 0 || dilation2 < 1 || C2 % CV_BK != 0)
+    return DLMCQ_EINVAL;
+  if (N > 0 && (!x2 || !w2 || !wsum2 || !in_scale2 || !w_scale2)) return DLMCQ_EINVAL;
+  if (!aligned16(x2) || !aligned16(w2)) return DLMCQ_EALIGN;
+  if (N * H2 * W2 * C2 >= (1ll << 40)) return DLMCQ_ERANGE;
+  ConvSeg2 s2{};
+  s2.x = static_cast<const int8_t*>(x2);
+  s2.w = w2;
+  s2.bias = bias2;
+  s2.wsum = wsum2;
+  s2.s_in = in_scale2;
+  s2.zp_in = in_zero_point2;
+  s2.s_w = w_scale2;
+  s2.shift = x2_is_unsigned ? 128 : 0;
+  ConvGeom& g = s2.g;
+  const int64_t P = (H2 + 2 * pad2 - dilation2 * (R2 - 1) - 1) / stride2 + 1;
+  const int64_t Q = (W2 + 2 * pad2 - dilation2 * (S2 - 1) - 1) / stride2 + 1;
+  if (P < 1 || Q < 1) return DLMCQ_EINVAL;
+  g.N = (int)N; g.H = (int)H2; g.W = (int)W2; g.C = (int)C2; g.K = (int)K; g.R = (int)R2; g.S = (int)S2;
+  g.stride = stride2; g.pad = pad2; g.dil = dilation2; g.P = (int)P; g.Q = (int)Q; g.M = N * P * Q;
+  g.qdiv = make_fastdiv((uint32_t)Q);
+  g.pdiv = make_fastdiv((uint32_t)P);
+  ConvEpi ep{};
+  ep.relu = relu != 0;
+  ep.codes = static_cast<uint8_t*>(codes);
+  ep.q_scale = q_scale;
+  ep.q_zp = q_zero_point;
+  ep.q_lo = (float)q_lo;
+  ep.q_hi = (float)q_hi;
+  ep.q_g = q_ste_g;
+  ep.q_form = q_form;
+  return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
+                     x_is_unsigned, stream, 1, ep, &s2);
 }
 
 // NOT part of the ABI (absent from include/dlmcq.h): the same call with an explicit kernel variant, for the tests and

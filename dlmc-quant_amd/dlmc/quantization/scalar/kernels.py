@@ -367,6 +367,58 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
     return out
 
 
+def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True):
+    """conv(a) + conv(b) in one kernel (dlmcq_conv2d_i8_nhwc_dual).  `a`, `b`: dicts with codes, wq, wsum, bias,
+    in_scale, in_zp, w_scale and optional stride / padding / dilation; both must produce the same output shape.
+    Returns fp32 (N, K, P, Q) channels_last, or `(out, codes)` with `emit` (see conv2d_i8)."""
+    def prep(t):
+        c = t["codes"]
+        N.require_gpu(c, t["wq"])
+        if c.dim() != 4:
+            raise ValueError("conv2d_i8_dual takes 4-D activation codes")
+        if not c.is_contiguous(memory_format=torch.channels_last):
+            c = c.contiguous(memory_format=torch.channels_last)
+        n, ch, h, w_ = c.shape
+        K_, R, S, _ = t["wq"].shape
+        st, pd, dl = int(t.get("stride", 1)), int(t.get("padding", 0)), int(t.get("dilation", 1))
+        P, Q = (h + 2 * pd - dl * (R - 1) - 1) // st + 1, (w_ + 2 * pd - dl * (S - 1) - 1) // st + 1
+        ws = _f32c(t["w_scale"].detach(), c).reshape(-1)
+        if ws.numel() == 1:
+            ws = ws.expand(K_).contiguous()
+        keep = (c, ws, _f32c(t["in_scale"].detach(), c).reshape(-1), None if t["in_zp"] is None else _f32c(t["in_zp"], c).reshape(-1),
+                None if t["bias"] is None else t["bias"].detach().contiguous())
+        return keep, (n, K_, P, Q), (h, w_, ch, R, S, st, pd, dl, int(c.dtype == torch.uint8))
+    (ca, wsa, sia, zpa, ba), shape_a, ga = prep(a)
+    (cb, wsb, sib, zpb, bb), shape_b, gb = prep(b)
+    if shape_a != shape_b:
+        raise ValueError(f"conv2d_i8_dual: the two convolutions give {shape_a} and {shape_b}")
+    if not want_out and emit is None:
+        raise ValueError("conv2d_i8_dual: nothing to produce (want_out=False without emit)")
+    n, K_, P, Q = shape_a
+
+    def alloc(dtype):
+        return torch.empty(shape_a, dtype=dtype, device=ca.device, memory_format=torch.channels_last)
+    out = alloc(torch.float32) if want_out else None
+    out_codes = q_scale = q_zp = None
+    lo = hi = form = 0
+    g = 0.0
+    if emit is not None:
+        out_codes = alloc(emit.dtype)
+        q_scale = _f32c(emit.scale.detach(), ca).reshape(-1)
+        q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, ca).reshape(-1)
+        lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
+    h, w_, ch, R, S, st, pd, dl, uns = ga
+    h2, w2, ch2, R2, S2, st2, pd2, dl2, uns2 = gb
+    oe = n * K_ * P * Q
+    nbytes = ca.numel() * (1 if st == 1 else 1) + cb.numel() + a["wq"].numel() + b["wq"].numel() + oe * (4 * want_out + (emit is not None))
+    PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_dual(
+        N.ptr(ca), N.ptr(a["wq"]), N.ptr(out), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa),
+        n, h, w_, ch, K_, R, S, st, pd, dl, uns,
+        N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2, ch2, R2, S2, st2, pd2, dl2,
+        uns2, int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())))
+    return (out, out_codes) if emit is not None else out
+
+
 def quantize_pad_nhwc4(x, scale, zero_point, lo, hi, form, pad, g=0.0):
     """Image batch (N, C <= 4, H, W) fp32, any memory format -> activation codes in a zero-point-padded NHWC
     buffer, 4 bytes per pixel: uint8/int8 tensor (N, H + 2 pad, W + 2 pad, 4) (a view of a slightly larger

@@ -32,7 +32,7 @@ from ..quantization.scalar.FSPTQuant.base import FSPTQBase
 from ..quantization.scalar.modules.base import QBase
 from ..quantization.scalar.RootQ.base import RootQBase
 
-__all__ = ["fuse_inference", "Int8Layer", "StemLayer", "FusionReport"]
+__all__ = ["fuse_inference", "Int8Layer", "DualInt8Layer", "StemLayer", "FusionReport"]
 
 
 # ---------------------------------------------------------------------------------- frozen quantiser specs
@@ -148,6 +148,34 @@ class Int8Layer(_PlanLayer):
         self.register_buffer("wq", wq, persistent=False)
         self.register_buffer("wsum", wsum, persistent=False)
 
+    def _codes(self, x):
+        """The activation codes of `x` (already codes, or fp32 quantised here in one pass)."""
+        act = self.act
+        if x.dtype in (torch.uint8, torch.int8):
+            return x
+        N.require_gpu(x)
+        if x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        return K.fake_quant(x, act.scale, act.zp, act.lo, act.hi, act.form, g=act.g(x.numel()), codes="i8", want_y=False)[1]
+
+    def _conv_kw(self):
+        lay = self.layer
+        return {} if lay.weight.dim() == 2 else dict(stride=lay.stride[0], padding=lay.padding[0], dilation=lay.dilation[0])
+
+    def _out_hw(self, codes):
+        lay = self.layer
+        if lay.weight.dim() == 2:
+            return 1, 1
+        st, pd, dl = lay.stride[0], lay.padding[0], lay.dilation[0]
+        r, s = lay.weight.shape[2], lay.weight.shape[3]
+        return (codes.shape[2] + 2 * pd - dl * (r - 1) - 1) // st + 1, (codes.shape[3] + 2 * pd - dl * (s - 1) - 1) // st + 1
+
+    def operand(self, x):
+        """This layer as one addend of conv2d_i8_dual."""
+        codes = self._codes(x)
+        return dict(codes=codes, wq=self.wq, wsum=self.wsum, bias=self.layer.bias, in_scale=self._in_scale(codes.numel()),
+                    in_zp=self.act.zp, w_scale=self.w_scale, **self._conv_kw())
+
     def forward(self, x, residual=None):
         lay, act = self.layer, self.act
         linear = lay.weight.dim() == 2
@@ -157,23 +185,10 @@ class Int8Layer(_PlanLayer):
             x = x.reshape(-1, x.shape[-1])
             if residual is not None:
                 residual = residual.reshape(-1, residual.shape[-1])
-        numel = x.numel()
-        if x.dtype in (torch.uint8, torch.int8):
-            codes = x
-        else:
-            N.require_gpu(x)
-            if x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
-                x = x.contiguous(memory_format=torch.channels_last)
-            _, codes = K.fake_quant(x, act.scale, act.zp, act.lo, act.hi, act.form, g=act.g(numel), codes="i8", want_y=False)
-        k = lay.weight.shape[0]
-        if linear:
-            kw, emit = {}, self._emit_for(codes.shape[0], k, 1, 1)
-        else:
-            st, pd, dl = lay.stride[0], lay.padding[0], lay.dilation[0]
-            kw = dict(stride=st, padding=pd, dilation=dl)
-            r, s = lay.weight.shape[2], lay.weight.shape[3]
-            emit = self._emit_for(codes.shape[0], k, (codes.shape[2] + 2 * pd - dl * (r - 1) - 1) // st + 1,
-                                  (codes.shape[3] + 2 * pd - dl * (s - 1) - 1) // st + 1)
+        codes = self._codes(x)
+        numel = codes.numel()
+        emit = self._emit_for(codes.shape[0], lay.weight.shape[0], *self._out_hw(codes))
+        kw = self._conv_kw()
         if self.relu or residual is not None or emit is not None:
             res = K.conv2d_i8(codes, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale,
                               residual=residual, relu=self.relu, emit=emit, want_out=self.want_out, **kw)
@@ -184,6 +199,23 @@ class Int8Layer(_PlanLayer):
             out = None if out is None else out.reshape(*lead, out.shape[-1])
             out_codes = None if out_codes is None else out_codes.reshape(*lead, out_codes.shape[-1])
         return self._finish(out, out_codes)
+
+
+class DualInt8Layer(nn.Module):
+    """`conv_a(x) + conv_b(y)` -> (ReLU) -> codes as ONE kernel: the last convolution of a residual block's first
+    unit and the convolution on its shortcut.  Neither addend is written to memory."""
+
+    def __init__(self, a, b):
+        super().__init__()
+        self.a, self.b = a, b          # `a` carries the epilogue options (relu / emit / want_out / pool)
+
+    def forward(self, x, y):
+        a = self.a
+        oa, ob = a.operand(x), self.b.operand(y)
+        emit = a._emit_for(oa["codes"].shape[0], a.layer.weight.shape[0], *a._out_hw(oa["codes"]))
+        res = K.conv2d_i8_dual(oa, ob, relu=a.relu, emit=emit, want_out=a.want_out)
+        out, out_codes = res if emit is not None else (res, None)
+        return a._finish(out, out_codes)
 
 
 class StemLayer(_PlanLayer):
@@ -213,13 +245,13 @@ class FusionReport:
     """What the pass did, for logs and tests."""
 
     def __init__(self):
-        self.layers = self.relu = self.residual = self.emit = self.fp32_outputs = self.stem = self.pooled = 0
+        self.layers = self.relu = self.residual = self.emit = self.fp32_outputs = self.stem = self.pooled = self.dual = 0
         self.skipped = []
 
     def __repr__(self):
         return (f"FusionReport(int8 layers={self.layers}, relu fused={self.relu}, residual fused={self.residual}, "
                 f"code-emitting={self.emit}, fp32 outputs kept={self.fp32_outputs}, stem layers={self.stem}, "
-                f"pools on codes={self.pooled}, not eligible={self.skipped})")
+                f"pools on codes={self.pooled}, dual (conv + shortcut conv) kernels={self.dual}, not eligible={self.skipped})")
 
 
 class _Tracer(fx.Tracer):
@@ -289,8 +321,21 @@ def fuse_inference(model, report=None):
             node.replace_all_uses_with(node.args[0])
             graph.erase_node(node)
 
+    dual_inputs = {}   # dual plan node -> (activation spec of input 0, of input 1)
+
+    def accepts(u, t):
+        """The activation quantiser `u` applies to tensor `t`, if `u` can take `t` as codes instead."""
+        if u in dual_inputs:
+            acts = {dual_inputs[u][i].key: dual_inputs[u][i] for i in (0, 1) if u.args[i] is t}
+            return next(iter(acts.values())) if len(acts) == 1 else None
+        s = spec_of(u) if u.args and u.args[0] is t else None
+        return s[0] if s is not None and s[4] == "gemm" else None
+
     count = 0
+    live = set(graph.nodes)
     for node in list(graph.nodes):
+        if node not in live:            # absorbed into a dual kernel earlier in this loop
+            continue
         spec = spec_of(node)
         if spec is None:
             continue
@@ -312,8 +357,8 @@ def fuse_inference(model, report=None):
         pool = None
         if len(users) == 1 and _pool_params(users[0], modules) is not None and modules[node.target].weight.shape[0] % 4 == 0:
             mp = users[0]
-            cons = [spec_of(u) if u.args and u.args[0] is mp else None for u in mp.users]
-            if cons and all(c is not None and c[4] == "gemm" for c in cons) and len({c[0].key for c in cons}) == 1:
+            cons = [accepts(u, mp) for u in mp.users]
+            if cons and all(c is not None for c in cons) and len({c.key for c in cons}) == 1:
                 pool = _pool_params(mp, modules)
                 chain.append(mp)
                 last = mp
@@ -321,11 +366,11 @@ def fuse_inference(model, report=None):
         consumers = {}
         fp32_needed = False
         for u in last.users:
-            s = spec_of(u) if u.args and u.args[0] is last else None
-            if s is None or s[4] != "gemm":
+            a = accepts(u, last)
+            if a is None:
                 fp32_needed = True
             else:
-                consumers.setdefault(s[0].key, []).append((u, s[0]))
+                consumers.setdefault(a.key, []).append((u, a))
         emit, takers = None, []
         if consumers:
             key = max(consumers, key=lambda k: len(consumers[k]))
@@ -339,9 +384,25 @@ def fuse_inference(model, report=None):
         specs[name] = None
         modules[name] = None
         cls = Int8Layer if spec[4] == "gemm" else StemLayer
-        gm.add_module(name, cls(modules[node.target], spec, relu=relu, emit=emit, want_out=fp32_needed or emit is None, pool=pool))
+        plan = cls(modules[node.target], spec, relu=relu, emit=emit, want_out=fp32_needed or emit is None, pool=pool)
+        # the shortcut is itself a not-yet-planned int8 convolution read by nobody else: one dual kernel
+        other = spec_of(residual) if residual is not None and residual.op == "call_module" else None
+        dual = (other is not None and other[4] == "gemm" and list(residual.users) == [chain[1]] and
+                modules[node.target].weight.dim() == 4 and modules[residual.target].weight.dim() == 4)
+        if dual:
+            gm.add_module(name, DualInt8Layer(plan, Int8Layer(modules[residual.target], other)))
+            args = (node.args[0], residual.args[0])
+        else:
+            gm.add_module(name, plan)
+            args = (node.args[0],) if residual is None else (node.args[0], residual)
         with graph.inserting_after(last):
-            fused = graph.call_module(name, args=(node.args[0],) if residual is None else (node.args[0], residual))
+            fused = graph.call_module(name, args=args)
+        if dual:
+            dual_inputs[fused] = (spec[0], other[0])
+            chain.insert(0, residual)       # erased last (its only user, the add, goes first)
+            specs[residual.target] = None   # never planned on its own
+            report.layers += 1
+            report.dual += 1
         with graph.inserting_after(fused):
             out = graph.call_function(operator.getitem, (fused, 0))
             codes = graph.call_function(operator.getitem, (fused, 1))
@@ -349,8 +410,11 @@ def fuse_inference(model, report=None):
             if u in (out, codes):
                 continue
             u.replace_input_with(last, codes if u in takers else out)
-        for n in reversed(chain):
+        for n in reversed(chain[1:] if dual else chain):
             graph.erase_node(n)
+        if dual:
+            graph.erase_node(residual)
+            live.discard(residual)
         report.layers += 1
         report.stem += spec[4] == "stem"
         report.pooled += pool is not None

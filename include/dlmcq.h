@@ -279,6 +279,25 @@ int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float* out, const
                                const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
                                int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
 
+/*
+ * Two convolutions into ONE output: out = conv(x, w) + conv(x2, w2), each dequantised with its own scales and bias
+ * and summed in fp32 (one addition, as `out += identity` does it in a residual block whose shortcut is a
+ * convolution), then the epilogue of dlmcq_conv2d_i8_nhwc_fused.  Both pairs must give the same [N, P, Q, K] output;
+ * the second pair has its own input size, channel count, filter size, stride, padding and dilation (the 1x1/2
+ * downsample next to the block's last 1x1).  Neither addend is written to memory.
+ */
+int dlmcq_conv2d_i8_nhwc_dual(const void* x, const int8_t* w, float* out, const float* bias,
+                              const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                              const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
+                              int64_t R, int64_t S, int32_t stride, int32_t pad, int32_t dilation,
+                              int32_t x_is_unsigned, const void* x2, const int8_t* w2, const float* bias2,
+                              const int32_t* wsum2, const float* in_scale2, const float* in_zero_point2,
+                              const float* w_scale2, int64_t H2, int64_t W2, int64_t C2, int64_t R2,
+                              int64_t S2, int32_t stride2, int32_t pad2, int32_t dilation2,
+                              int32_t x2_is_unsigned, int32_t relu, void* codes, const float* q_scale,
+                              const float* q_zero_point, int32_t q_lo, int32_t q_hi, int32_t q_form,
+                              float q_ste_g, dlmcq_stream_t stream);
+
 /* ---- the 3-channel first layer and its max-pool, in the integer-code domain (csrc/conv_stem_i8.hip) ---- */
 
 /*

@@ -77,6 +77,51 @@ def test_fused_epilogue_equals_the_separate_kernels(form):
                          want, tag + " no-emit")
 
 
+def test_dual_kernel_equals_two_convolutions_and_an_add():
+    """conv_a(x) + conv_b(y) (the block's last conv + the conv on its shortcut) in one kernel, every epilogue."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    cases = [  # (N, Ca, Ha, Ka, Ra, stride_a, pad_a), (Cb, Hb, Rb, stride_b, pad_b)
+        ((2, 64, 14, 256, 1, 1, 0), (128, 28, 1, 2, 0)),     # Bottleneck: 1x1 + 1x1/2 downsample
+        ((3, 128, 9, 128, 3, 1, 1), (64, 18, 1, 2, 0)),      # BasicBlock: 3x3 + 1x1/2 downsample, ragged M
+        ((2, 64, 12, 64, 1, 1, 0), (64, 12, 3, 1, 1)),       # BN = 64 tiles, 3x3 on the shortcut
+        ((1, 192, 7, 192, 1, 1, 0), (64, 7, 1, 1, 0)),       # K % 128 != 0
+    ]
+    for idx, ((n, ca, ha, k, ra, sa, pa), (cb, hb, rb, sb, pb)) in enumerate(cases):
+        gg = gen(400 + idx)
+
+        def operand(c, h, r, stride, pad, unsigned, seed_zp):
+            lo, hi = (0, 256) if unsigned else (-127, 128)
+            codes = torch.randint(lo, hi, (n, c, h, h), generator=gg).to(torch.uint8 if unsigned else torch.int8).to(DEV)
+            codes = codes.contiguous(memory_format=torch.channels_last)
+            wt = (torch.randn(k, c, r, r, generator=gg) * 0.05).to(DEV)
+            s_w = wt.abs().amax(dim=(1, 2, 3)) / 127 + 1e-6
+            wq, wsum = K.quantize_weight_krsc(wt, s_w, -127, 127)
+            return dict(codes=codes, wq=wq, wsum=wsum, bias=torch.randn(k, generator=gg).to(DEV),
+                        in_scale=torch.tensor([0.0173 + 0.001 * seed_zp], device=DEV),
+                        in_zp=torch.tensor([float(seed_zp) if unsigned else 0.0], device=DEV), w_scale=s_w, stride=stride, padding=pad)
+        a = operand(ca, ha, ra, sa, pa, True, 2)
+        b = operand(cb, hb, rb, sb, pb, idx % 2 == 0, 5)
+
+        def single(t):
+            return K.conv2d_i8(t["codes"], t["wq"], t["wsum"], t["bias"], t["in_scale"], t["in_zp"], t["w_scale"],
+                               stride=t["stride"], padding=t["padding"])
+        plain = single(a) + single(b)
+        same(K.conv2d_i8_dual(a, b), plain, f"dual case {idx} plain")
+        q_s = torch.tensor([float(plain.abs().max()) / 255 * 0.7], device=DEV)
+        emit = K.EmitCodes(q_s, torch.tensor([1.0], device=DEV), 0, 255, N.FORM_ZEROPOINT)
+        want = torch.relu(plain)
+        _, wc = K.fake_quant(want, q_s, emit.zero_point, 0, 255, N.FORM_ZEROPOINT, codes="i8", want_y=False)
+        out, codes = K.conv2d_i8_dual(a, b, relu=True, emit=emit)
+        same(out, want, f"dual case {idx} relu out")
+        same(codes, wc, f"dual case {idx} codes")
+        none, codes2 = K.conv2d_i8_dual(a, b, relu=True, emit=emit, want_out=False)
+        assert none is None
+        same(codes2, wc, f"dual case {idx} codes-only")
+    with pytest.raises(ValueError):     # different output shapes
+        K.conv2d_i8_dual(a, dict(b, stride=2))
+
+
 def test_fused_entry_rejects_bad_arguments():
     from dlmc import _native as N
     from dlmc.quantization.scalar import kernels as K
@@ -135,7 +180,8 @@ def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res, sign
     if arch == "resnet50":
         assert rep.layers == 54 and rep.residual == 16 and rep.relu == 49 and rep.skipped == []
         assert rep.stem == 1 and rep.pooled == 1           # conv1 -> ReLU -> max-pool, pooled as codes
-        assert rep.emit == 48 and rep.fp32_outputs == 18   # 12 shortcuts + 4 residual feeds + last block + fc
+        assert rep.emit == 48 and rep.fp32_outputs == 14   # 12 shortcuts + last block + fc
+        assert rep.dual == 4                               # conv3 + downsample of each stage's first block: one kernel
     if arch == "repvgg_a1":
         assert rep.layers == 23 and rep.relu == 22 and rep.stem == 1 and rep.skipped == []
         assert rep.fp32_outputs == 2    # the last block (feeds the pool) and the classifier

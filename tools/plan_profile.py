@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 import workloads as W  # noqa: E402
 from bench import QCFG  # noqa: E402
-from dlmc.utils.fuse import Int8Layer, fuse_inference  # noqa: E402
+from dlmc.utils.fuse import _PlanLayer as Int8Layer, fuse_inference  # noqa: E402
 from dlmc.utils.merge_bn import merge_bn  # noqa: E402
 from dlmc.utils.quantize import quantize_model  # noqa: E402
 
@@ -20,7 +20,7 @@ dev = "cuda:0"
 torch.manual_seed(2333)
 model = merge_bn(W.MODELS[name]().to(dev).eval(), inplace=True, allow_missing=True)
 quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=True)
-x = torch.randn(batch, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+x = torch.relu(torch.randn(batch, 3, 224, 224, device=dev)).contiguous(memory_format=torch.channels_last)
 recs = []
 with torch.no_grad():
     model(x)
