@@ -410,7 +410,9 @@ def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True):
     h, w_, ch, R, S, st, pd, dl, uns = ga
     h2, w2, ch2, R2, S2, st2, pd2, dl2, uns2 = gb
     oe = n * K_ * P * Q
-    nbytes = ca.numel() * (1 if st == 1 else 1) + cb.numel() + a["wq"].numel() + b["wq"].numel() + oe * (4 * want_out + (emit is not None))
+    def touched(c, r, s_, stride):     # a strided 1x1 convolution reads only the pixels it samples
+        return c.numel() // (stride * stride) if r == 1 and s_ == 1 else c.numel()
+    nbytes = touched(ca, R, S, st) + touched(cb, R2, S2, st2) + a["wq"].numel() + b["wq"].numel() + oe * (4 * want_out + (emit is not None))
     PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_dual(
         N.ptr(ca), N.ptr(a["wq"]), N.ptr(out), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa),
         n, h, w_, ch, K_, R, S, st, pd, dl, uns,

@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 import workloads as W  # noqa: E402
 from bench import QCFG  # noqa: E402
-from dlmc.utils.fuse import _PlanLayer as Int8Layer, fuse_inference  # noqa: E402
+from dlmc.utils.fuse import DualInt8Layer, _PlanLayer as Int8Layer, fuse_inference  # noqa: E402
 from dlmc.utils.merge_bn import merge_bn  # noqa: E402
 from dlmc.utils.quantize import quantize_model  # noqa: E402
 
@@ -36,8 +36,9 @@ with torch.no_grad():
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         recs.append((mod, args, out, mod._ev, e))
+    duals = [m for m in plan.modules() if isinstance(m, DualInt8Layer)]
     for m in plan.modules():
-        if isinstance(m, Int8Layer):
+        if isinstance(m, DualInt8Layer) or (isinstance(m, Int8Layer) and not any(m is d.a or m is d.b for d in duals)):
             m.register_forward_pre_hook(pre)
             m.register_forward_hook(post)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,9 +49,18 @@ with torch.no_grad():
 print(f"whole forward {a.elapsed_time(b):.2f} ms")
 tot = 0.0
 for mod, args, out, s, e in recs:
-    lay = mod.layer
     us = s.elapsed_time(e) * 1e3
     tot += us
+    if isinstance(mod, DualInt8Layer):
+        wa, wb = mod.a.layer.weight, mod.b.layer.weight
+        o = out[0] if out[0] is not None else out[1]
+        macs = o.numel() * (wa.numel() // wa.shape[0] + wb.numel() // wb.shape[0])
+        nb = args[0].numel() + args[1].numel() // (mod.b.layer.stride[0] ** 2) + wa.numel() + wb.numel() + o.numel() * (
+            4 * (out[0] is not None) + (out[1] is not None))
+        print(f"{us:8.1f} us  DUAL {str(tuple(args[0].shape)):20s} x {str(tuple(wa.shape)):18s} + {str(tuple(args[1].shape)):20s} x "
+              f"{str(tuple(wb.shape)):18s} {'out ' if out[0] is not None else '    '}codes  {2 * macs / us / 1e6:6.0f} TOP/s {nb / us / 1e3:6.0f} GB/s")
+        continue
+    lay = mod.layer
     xin = args[0]
     o = out[0] if out[0] is not None else out[1]
     w = lay.weight
