@@ -255,61 +255,91 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
   const int hsel = lane >> 5;
   i32x16 acc[MT][NT];
 
-  // One (input, weight) pair: the whole pipelined reduction into acc.  Called once, or twice when DUAL.
-  auto reduce = [&](const int8_t* __restrict__ x, const int8_t* __restrict__ w, const ConvGeom& g, int zpi, int shift) {
-  const int8_t* padline = g_pad_table.b + ((zpi & 0xff) << 4);   // stored UNshifted: the xor happens on read
-  const uint32_t xorw = shift ? 0x80808080u : 0u;
-
   // ---- DMA assignment: wave-instruction i of this wave covers tile rows (i*4 + wave)*16 .. +15 ----
   const int lrow = lane / SLOTS, pslot = lane % SLOTS;
-  int a_n[AI], a_h0[AI], a_w0[AI], a_seg[AI];
-  bool a_ok[AI];
+  int a_seg[AI], b_seg[BI];
 #pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int row = (i * 4 + wave) * RPI + lrow;
-    a_seg[i] = pslot ^ ((row / RPB) & (SLOTS - 1));
-    const int64_t m = m0 + row;
-    a_ok[i] = m < g.M;
-    row_origin(g, a_ok[i] ? (uint32_t)m : 0u, a_n[i], a_h0[i], a_w0[i]);
-  }
-  int b_seg[BI];
-  const int8_t* b_src[BI];
-  const int64_t wrow = (int64_t)g.R * g.S * g.C;
+  for (int i = 0; i < AI; ++i) a_seg[i] = pslot ^ ((((i * 4 + wave) * RPI + lrow) / RPB) & (SLOTS - 1));
 #pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    const int row = (i * 4 + wave) * RPI + lrow;
-    b_seg[i] = pslot ^ ((row / RPB) & (SLOTS - 1));
-    const int k = n0 + row;
-    b_src[i] = k < g.K ? w + (int64_t)k * wrow : nullptr;
-  }
-  const int cchunks = g.C / BK;
-  const int nsteps = g.R * g.S * cchunks;
+  for (int i = 0; i < BI; ++i) b_seg[i] = pslot ^ ((((i * 4 + wave) * RPI + lrow) / RPB) & (SLOTS - 1));
 
-  int f_cc = 0, f_s = 0, f_r = 0, f_buf = 0;
-  auto issue = [&]() {
-    int8_t* base = lds + f_buf * TILE;
-    const int rs = f_r * g.S + f_s;
+  // One (input, weight) pair as a source of K steps.  DUAL kernels have two; their steps form ONE sequence through the
+  // same LDS ring (the second pair's first steps are already in flight while the first pair's last steps multiply).
+  struct Feed {
+    const int8_t* x;
+    const int8_t* padline;     // stored UNshifted: the xor happens on read
+    const int8_t* b_src[BI];
+    int a_n[AI], a_h0[AI], a_w0[AI];
+    bool a_ok[AI];
+    int cc, s, r, cchunks, nsteps;
+    uint32_t xorw;
+  };
+  auto make_feed = [&](Feed& f, const int8_t* __restrict__ xx, const int8_t* __restrict__ ww, const ConvGeom& gg, int zpi,
+                       int shf) {
+    f.x = xx;
+    f.padline = g_pad_table.b + ((zpi & 0xff) << 4);
+    f.xorw = shf ? 0x80808080u : 0u;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int h = a_h0[i] + f_r * g.dil, ww = a_w0[i] + f_s * g.dil;
-      const int8_t* src = padline;
-      if (a_ok[i] && h >= 0 && h < g.H && ww >= 0 && ww < g.W)
-        src = x + (((int64_t)a_n[i] * g.H + h) * g.W + ww) * g.C + f_cc * BK + a_seg[i] * 16;
+      const int64_t m = m0 + (i * 4 + wave) * RPI + lrow;
+      f.a_ok[i] = m < gg.M;
+      row_origin(gg, f.a_ok[i] ? (uint32_t)m : 0u, f.a_n[i], f.a_h0[i], f.a_w0[i]);
+    }
+    const int64_t wrow = (int64_t)gg.R * gg.S * gg.C;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int k = n0 + (i * 4 + wave) * RPI + lrow;
+      f.b_src[i] = k < gg.K ? ww + (int64_t)k * wrow : nullptr;
+    }
+    f.cc = f.s = f.r = 0;
+    f.cchunks = gg.C / BK;
+    f.nsteps = gg.R * gg.S * f.cchunks;
+  };
+  int f_buf = 0;
+  auto issue = [&](Feed& f, const ConvGeom& gg) {
+    int8_t* base = lds + f_buf * TILE;
+    const int rs = f.r * gg.S + f.s;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int h = f.a_h0[i] + f.r * gg.dil, ww = f.a_w0[i] + f.s * gg.dil;
+      const int8_t* src = f.padline;
+      if (f.a_ok[i] && h >= 0 && h < gg.H && ww >= 0 && ww < gg.W)
+        src = f.x + (((int64_t)f.a_n[i] * gg.H + h) * gg.W + ww) * gg.C + f.cc * BK + a_seg[i] * 16;
       if (!(ABL & 8)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int8_t* src = b_src[i] ? b_src[i] + (int64_t)rs * g.C + f_cc * BK + b_seg[i] * 16 : g_pad_table.b;
+      const int8_t* src = f.b_src[i] ? f.b_src[i] + (int64_t)rs * gg.C + f.cc * BK + b_seg[i] * 16 : g_pad_table.b;
       if (!(ABL & 16)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + TILE_A + (i * 4 + wave) * 1024), 16, 0, 0);
     }
-    if (++f_cc == cchunks) {
-      f_cc = 0;
-      if (++f_s == g.S) {
-        f_s = 0;
-        ++f_r;
+    if (++f.cc == f.cchunks) {
+      f.cc = 0;
+      if (++f.s == gg.S) {
+        f.s = 0;
+        ++f.r;
       }
     }
     if (++f_buf == NBUF) f_buf = 0;
+  };
+
+  const float zpf = zp_in ? zp_in[0] : 0.0f;
+  const int zpi = (int)__builtin_rintf(zpf);
+  Feed fm;                                   // the layer's own pair
+  make_feed(fm, x, w, g, zpi, shift);
+  Feed fs;                                   // DUAL: the shortcut pair, reduced FIRST (its sum waits in registers)
+  int zpi2 = 0;
+  if (DUAL) {
+    const float zf2 = sg.zp_in ? sg.zp_in[0] : 0.0f;
+    zpi2 = (int)__builtin_rintf(zf2);
+    make_feed(fs, sg.x, sg.w, sg.g, zpi2, sg.shift);
+  }
+  const int nfirst = DUAL ? fs.nsteps : 0;
+  const int nsteps = nfirst + fm.nsteps;
+  int issued = 0;
+  auto issue_next = [&]() {
+    if (DUAL && issued < nfirst) issue(fs, sg.g);
+    else issue(fm, g);
+    ++issued;
   };
 
 #pragma unroll
@@ -318,10 +348,11 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mi][j][i] = 0;
+  float extra[DUAL ? MT : 1][DUAL ? NT : 1][16];
 
 #pragma unroll
   for (int i = 0; i < PF; ++i)
-    if (i < nsteps) issue();
+    if (i < nsteps) issue_next();
   int c_buf = 0;
   for (int step = 0; step < nsteps; ++step) {
     // step's own DMAs must have landed; the next step's group (AI + BI instructions) may stay in flight
@@ -341,24 +372,44 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: drain (conservative)
     }
     __builtin_amdgcn_s_barrier();                 // everyone's step-k bytes are in LDS; everyone left multiply(k-1)
-    if (!(ABL & 1) && step + PF < nsteps) issue();  // into the buffer multiply(k-1) just released
+    if (!(ABL & 1) && step + PF < nsteps) issue_next();  // into the buffer multiply(k-1) just released
+    if (DUAL && step == nfirst) {
+      // the shortcut pair is complete: dequantise its sum into registers and start the layer's own sum from zero
+      const float sin2 = sg.s_in[0];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + j * 32 + (lane & 31);
+        const bool cok = col < g.K;
+        const float mult = cok ? sin2 * sg.s_w[col] : 0.0f;
+        const int corr = cok ? (sg.shift - zpi2) * sg.wsum[col] : 0;
+        const float bv = (cok && sg.bias) ? sg.bias[col] : 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < (DUAL ? MT : 1); ++mi)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            extra[mi][DUAL ? j : 0][i] = (float)(acc[mi][j][i] + corr) * mult + bv;
+            acc[mi][j][i] = 0;
+          }
+      }
+    }
+    const uint32_t xorw = (DUAL && step < nfirst) ? fs.xorw : fm.xorw;
     const int8_t* base = lds + c_buf * TILE;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      const int sg = ks * 2 + hsel;
+      const int sg_ = ks * 2 + hsel;
       i32x4 af[MT];
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
         const int arow = wrow0 + mi * 32 + (lane & 31);
         const i32x4 t = (ABL & 4) ? i32x4{lane, step, ks, mi}
-                                  : *reinterpret_cast<const i32x4*>(base + arow * BK + ((sg ^ ((arow / RPB) & (SLOTS - 1))) << 4));
+                                  : *reinterpret_cast<const i32x4*>(base + arow * BK + ((sg_ ^ ((arow / RPB) & (SLOTS - 1))) << 4));
         af[mi] = i32x4{(int)(t.x ^ xorw), (int)(t.y ^ xorw), (int)(t.z ^ xorw), (int)(t.w ^ xorw)};
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int brow = j * 32 + (lane & 31);
         const i32x4 bf = (ABL & 4) ? i32x4{j, lane, step, ks}
-                                   : *reinterpret_cast<const i32x4*>(base + TILE_A + brow * BK + ((sg ^ ((brow / RPB) & (SLOTS - 1))) << 4));
+                                   : *reinterpret_cast<const i32x4*>(base + TILE_A + brow * BK + ((sg_ ^ ((brow / RPB) & (SLOTS - 1))) << 4));
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
           if (ABL & 2) {
@@ -372,32 +423,6 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
     }
     if (++c_buf == NBUF) c_buf = 0;
   }
-  };   // reduce
-
-  // the shortcut pair first: its dequantised sum waits in registers while the main pair reduces
-  float extra[DUAL ? MT : 1][DUAL ? NT : 1][16];
-  if (DUAL) {
-    const float zf2 = sg.zp_in ? sg.zp_in[0] : 0.0f;
-    const int zpi2 = (int)__builtin_rintf(zf2);
-    reduce(sg.x, sg.w, sg.g, zpi2, sg.shift);
-    const float sin2 = sg.s_in[0];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + j * 32 + (lane & 31);
-      const bool cok = col < g.K;
-      const float mult = cok ? sin2 * sg.s_w[col] : 0.0f;
-      const int corr = cok ? (sg.shift - zpi2) * sg.wsum[col] : 0;
-      const float bv = (cok && sg.bias) ? sg.bias[col] : 0.0f;
-#pragma unroll
-      for (int mi = 0; mi < (DUAL ? MT : 1); ++mi)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) extra[mi][DUAL ? j : 0][i] = (float)(acc[mi][j][i] + corr) * mult + bv;
-    }
-    __builtin_amdgcn_s_barrier();   // every wave has left the ring before the main pair refills it
-  }
-  const float zpf = zp_in ? zp_in[0] : 0.0f;
-  const int zpi = (int)__builtin_rintf(zpf);
-  reduce(x, w, g, zpi, shift);
 
   const float sin = s_in[0];
   const EpiQuant eq(ep);

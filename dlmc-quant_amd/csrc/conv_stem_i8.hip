@@ -195,33 +195,58 @@ struct PoolGeom {
   FastDiv cdiv, qdiv, pdiv;
 };
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// running bytewise maximum of dwords, kept as two packed-u16 halves (even bytes, odd bytes): v_pk_max_u16
+struct ByteMax {
+  uint32_t even = 0, odd = 0;
+  __device__ __forceinline__ void take(uint32_t v) {
+    const uint32_t e = v & 0x00ff00ffu, o = (v >> 8) & 0x00ff00ffu;
+    even = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, even), __builtin_bit_cast(u16x2, e)));
+    odd = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, odd), __builtin_bit_cast(u16x2, o)));
+  }
+  __device__ __forceinline__ uint32_t get() const { return even | (odd << 8); }
+};
+
+// one thread = V dwords (4 V channels) of one output pixel; signed codes are compared as unsigned after flipping the
+// sign bit; padding never wins: the lowest code is 0 after the flip
+template <int V>
 __global__ __launch_bounds__(DLMCQ_BLOCK) void maxpool_codes_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ y,
                                                                     PoolGeom g, uint32_t flip) {
-  // one thread = 4 channels of one output pixel; signed codes are compared as unsigned after flipping the sign bit
-  const int64_t total = (int64_t)g.N * g.P * g.Q * g.C4;
+  const int cv = g.C4 / V;   // vectors per pixel (g.cdiv divides by this)
+  const int64_t total = (int64_t)g.N * g.P * g.Q * cv;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t pix = fdiv((uint32_t)i, g.cdiv);
-    const int c4 = (int)((uint32_t)i - pix * (uint32_t)g.C4);
+    const int c = (int)((uint32_t)i - pix * (uint32_t)cv) * V;
     const uint32_t t = fdiv(pix, g.qdiv);
     const int q = (int)(pix - t * (uint32_t)g.Q);
     const uint32_t n = fdiv(t, g.pdiv);
     const int p = (int)(t - n * (uint32_t)g.P);
     const int h0 = p * g.stride - g.pad, w0 = q * g.stride - g.pad;
-    uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;   // padding never wins: the lowest code is 0 after the flip
+    ByteMax m[V];
     for (int dh = 0; dh < g.k; ++dh) {
       const int h = h0 + dh;
       if (h < 0 || h >= g.H) continue;
       for (int dw = 0; dw < g.k; ++dw) {
         const int w = w0 + dw;
         if (w < 0 || w >= g.W) continue;
-        const uint32_t v = x[(((int64_t)n * g.H + h) * g.W + w) * g.C4 + c4] ^ flip;
-        b0 = max(b0, v & 0xffu);
-        b1 = max(b1, (v >> 8) & 0xffu);
-        b2 = max(b2, (v >> 16) & 0xffu);
-        b3 = max(b3, v >> 24);
+        const uint32_t* src = x + (((int64_t)n * g.H + h) * g.W + w) * g.C4 + c;
+        if (V == 4) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(src);
+          m[0].take(v.x ^ flip);
+          m[1 % V].take(v.y ^ flip);
+          m[2 % V].take(v.z ^ flip);
+          m[3 % V].take(v.w ^ flip);
+        } else {
+          m[0].take(src[0] ^ flip);
+        }
       }
     }
-    y[i] = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) ^ flip;
+    uint32_t* dst = y + (int64_t)pix * g.C4 + c;
+    if (V == 4) __builtin_nontemporal_store(u32x4{m[0].get() ^ flip, m[1 % V].get() ^ flip, m[2 % V].get() ^ flip, m[3 % V].get() ^ flip},
+                                            reinterpret_cast<u32x4*>(dst));
+    else dst[0] = m[0].get() ^ flip;
   }
 }
 
@@ -325,17 +350,20 @@ extern "C" int dlmcq_maxpool_codes_nhwc(const void* x, void* y, int64_t N, int64
   if (N == 0) return DLMCQ_OK;
   if (!x || !y) return DLMCQ_EINVAL;
   if (!aligned4(x) || !aligned4(y)) return DLMCQ_EALIGN;
-  const int64_t total = N * P * Q * (C / 4);
-  if (total >= (1ll << 31) || N * H * W * (C / 4) >= (1ll << 31)) return DLMCQ_ERANGE;
+  const bool vec = (C % 16) == 0 && aligned16(x) && aligned16(y);
+  const int64_t total = N * P * Q * (C / (vec ? 16 : 4));
+  if (N * P * Q * (C / 4) >= (1ll << 31) || N * H * W * (C / 4) >= (1ll << 31)) return DLMCQ_ERANGE;
   PoolGeom g;
   g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C4 = (int)(C / 4); g.k = kernel; g.stride = stride; g.pad = pad;
   g.P = (int)P; g.Q = (int)Q;
-  g.cdiv = make_fastdiv((uint32_t)g.C4);
+  g.cdiv = make_fastdiv((uint32_t)(vec ? g.C4 / 4 : g.C4));
   g.qdiv = make_fastdiv((uint32_t)Q);
   g.pdiv = make_fastdiv((uint32_t)P);
   const int64_t blocks = (total + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
-  hipLaunchKernelGGL(maxpool_codes_kernel, dim3((uint32_t)(blocks < 65536 ? blocks : 65536)), dim3(DLMCQ_BLOCK), 0,
-                     reinterpret_cast<hipStream_t>(stream), static_cast<const uint32_t*>(x), static_cast<uint32_t*>(y), g,
-                     x_is_unsigned ? 0u : 0x80808080u);
+  const dim3 grid((uint32_t)(blocks < 65536 ? blocks : 65536));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const uint32_t flip = x_is_unsigned ? 0u : 0x80808080u;
+  if (vec) hipLaunchKernelGGL((maxpool_codes_kernel<4>), grid, dim3(DLMCQ_BLOCK), 0, st, static_cast<const uint32_t*>(x), static_cast<uint32_t*>(y), g, flip);
+  else hipLaunchKernelGGL((maxpool_codes_kernel<1>), grid, dim3(DLMCQ_BLOCK), 0, st, static_cast<const uint32_t*>(x), static_cast<uint32_t*>(y), g, flip);
   return launch_status();
 }
