@@ -560,3 +560,44 @@ def test_output_aware_weight_scale_and_function_api(golden):
             assert wr.grad is not None and wr.grad.shape == w.shape
             if fn is not FunLQ:
                 assert_bits_equal(y, golden.get(c, "y"), fn.__name__)
+
+
+def test_block_reconstruction_stays_on_the_device():
+    """hooked activations collected in HBM, AdaRound optimised with the fused kernels; the block's
+    output error against its fp32 twin must drop."""
+    import copy
+    import workloads as W
+    from dlmc.quantization.scalar.FSPTQuant import FSPTQBase
+    from dlmc.utils.quantize import quantize_model
+    from dlmc.utils.reconstruct import collect_block_io, reconstruct_block
+    torch.manual_seed(2333)
+    from dlmc.utils.merge_bn import merge_bn
+    fp = merge_bn(W.resnet18().to(DEV).eval(), inplace=True)      # FSPTQuant.py:67: BN is folded before quantize_model
+    net = copy.deepcopy(fp)
+    cfg = {"weight": {"enable": True, "type": "minmax_channel", "recon_type": "adaround", "args": {"n_bits": 3, "signed": True}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+           "exclude_layers": [], "override_options": []}
+    quantize_model(net, cfg, None, "FSPTQ")
+    batches = [torch.relu(torch.randn(8, 3, 64, 64, device=DEV)) for _ in range(4)]
+    with torch.no_grad():
+        net(batches[0])                                   # calibrate (scales, alpha)
+    block, fp_block = net.layer1[0], fp.layer1[0]
+    xin, yout = collect_block_io(net, fp, block, fp_block, batches, total=32)
+    assert xin.is_cuda and yout.is_cuda and xin.shape == (32, 64, 16, 16) and yout.shape == (32, 64, 16, 16)
+    with pytest.raises(RuntimeError):
+        collect_block_io(net, fp, block, fp_block, batches, total=31)
+    for p in block.parameters():
+        p.requires_grad_(False)
+    for m in block.modules():
+        if isinstance(m, FSPTQBase):
+            m.alpha.requires_grad_(True)
+    block.train()                                          # the loop optimises the soft-rounded block (base.py:136-141)
+    with torch.no_grad():
+        before = float((block(xin) - yout).pow(2).mean())
+    groups = [{"params": [m.alpha for m in block.modules() if isinstance(m, FSPTQBase)], "lr": 1e-2}]
+    last = reconstruct_block(block, xin, yout, iters=80, batch=16, param_groups=groups)
+    assert block.training and torch.isfinite(last)
+    with torch.no_grad():
+        after = float((block(xin) - yout).pow(2).mean())
+    print(f"block reconstruction (soft rounding): l2 {before:.5f} -> {after:.5f}")
+    assert after < 0.9 * before

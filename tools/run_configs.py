@@ -86,21 +86,38 @@ def main():
             t0 = time.perf_counter()
             mc(xc)
             ts.append(time.perf_counter() - t0)
+    from dlmc.utils.fuse import fuse_inference
+    for mod in m.modules():
+        if hasattr(mod, "int8_gemm"):
+            mod.int8_gemm = True
+    plan = fuse_inference(m)
+    pfwd = GraphedForward(plan, x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        pfwd(x)
+    torch.cuda.synchronize()
+    plan_graph_ms = (time.perf_counter() - t0) / 50 * 1e3
     out["config1_resnet18_b1_w8a8_per_tensor"] = {"gpu_ms": round(dt * 1e3, 3), "gpu_images_per_s": round(1 / dt, 1),
                                                   "gpu_hipgraph_ms": round(graph_ms, 3),
+                                                  "gpu_fused_plan_hipgraph_ms": round(plan_graph_ms, 3),
                                                   "cpu_port_ms": round(statistics.median(ts) * 1e3, 1),
                                                   "cpu_cores": bench.usable_cores(), "kernels": fam}
     # ---- config 3 / 4
     for name, model_name, batch in (("config3_resnet50_b512", "resnet50", 512), ("config4_repvgg_a1_b512_per_gpu", "repvgg_a1", 512)):
-        for int8 in (True, False):
+        for mode in ("fused_plan", "int8_modules", "fp32conv_modules"):
+            int8 = mode != "fp32conv_modules"
             m = merge_bn(W.MODELS[model_name]().to(DEV).eval(), inplace=True, allow_missing=True)
             quantize_model(m, cfg("minmax_channel", 8, True), None, quantization_type="FSPTQ", int8_gemm=int8)
-            x = torch.randn(batch, 3, 224, 224, device=DEV)
+            x = torch.relu(torch.randn(batch, 3, 224, 224, device=DEV))     # unsigned-activation configs
             if int8:
                 x = x.contiguous(memory_format=torch.channels_last)
+            if mode == "fused_plan":
+                with torch.no_grad():
+                    m(x)
+                m = fuse_inference(m)
             dt, fam = time_model(m, x, 5)
-            out[f"{name}_{'int8' if int8 else 'fp32conv'}"] = {"ms_per_step": round(dt * 1e3, 2),
-                                                               "images_per_s": round(batch / dt, 1), "kernels": fam}
+            out[f"{name}_{mode}"] = {"ms_per_step": round(dt * 1e3, 2), "images_per_s": round(batch / dt, 1), "kernels": fam}
             del m, x
             torch.cuda.empty_cache()
     # ---- config 5
