@@ -55,7 +55,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(batch, budget_s=20.0, fold_bn=True):
+def cpu_baseline(batch, budget_s=20.0, fold_bn=True, halfnormal=True):
     """The reference's CPU path (port in oracle/ref_layers.py) on a bounded sample of the same workload."""
     import workloads as W
     from oracle.ref_layers import port_model
@@ -206,6 +206,21 @@ def main():
             r["note"] = note
         return r
 
+    def pmc_traffic(kernel_substr):
+        """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+        (profiles/*pmc_bench*.json, made by tools/pmc_summary.py --tail; FETCH_SIZE doubled as MI355X_MICROARCH.md
+        prescribes for 16-byte-per-lane streaming reads on gfx950).  None when no such file travels with the repo."""
+        import glob
+        for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_bench*.json")), reverse=True):
+            try:
+                d = json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            for k, v in d.items():
+                if k.startswith("TAIL") and kernel_substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                    return int((2 * v["FETCH_SIZE"]["mean_KiB"] + v["WRITE_SIZE"]["mean_KiB"]) * 1024), os.path.basename(path)
+        return None, None
+
     empty = {"launches": 0, "bytes": 0, "ms": 0.0}
     fq = fam.get("fq_tensor", empty)
     fq_roof = roof("fq_tensor", fq, "fq_tensor_kernel<ZEROPOINT> (per-tensor activation fake-quant"
@@ -229,6 +244,10 @@ def main():
                              "the fp32 output stream, the 3x3 layers by the MFMA pipeline (see conv_i8.TOPs)", ops=conv_ops)
     else:
         main_roof = fq_roof
+    if args.fused and conv["ms"] > fq["ms"] and args.model == "resnet50" and args.batch == 512:
+        main_roof["traffic"], src = pmc_traffic("conv_i8_dma_kernel")
+        if src:
+            main_roof["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
     qbytes = sum(f["bytes"] for k, f in fam.items() if k.startswith("fq"))
     qms = sum(f["ms"] for k, f in fam.items() if k.startswith("fq"))
     out = {
