@@ -197,11 +197,11 @@ __global__ __launch_bounds__(256, 2) void conv_i8_kernel(const int8_t* __restric
 //     16-byte segment p ^ ((r >> 2) & 3), and the fragment reads apply the same involution;
 //   * DMA cannot transform or synthesise bytes: the uint8 -> int8 shift (q ^ 0x80) is applied to the A fragment
 //     after the ds_read, and padded taps / rows beyond K read a 16-byte line of a constant table instead.
-struct PadTable {
-  int8_t b[256 * 16];
+struct PadTable {   // 64 bytes of every byte value: a padded tap reads its K chunks at offsets 0 / 32 of one line
+  int8_t b[256 * 64];
   constexpr PadTable() : b() {
     for (int v = 0; v < 256; ++v)
-      for (int j = 0; j < 16; ++j) b[v * 16 + j] = (int8_t)v;
+      for (int j = 0; j < 64; ++j) b[v * 64 + j] = (int8_t)v;
   }
 };
 __device__ const PadTable g_pad_table = PadTable();
@@ -290,11 +290,26 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
     bool a_ok[NA];
     int cc, s, r, cchunks, nsteps;
     uint32_t xorw;
+    // ADIR: running pointers, so that a K step costs two 64-bit adds per operand row instead of the whole
+    // (bounds check, pixel address, tap offset) computation - that arithmetic, not memory, was what bounded the loop
+    const int8_t* ap[NA];   // this lane's A bytes for the current tap and channel chunk (or the pad line)
+    int a_inc[NA];          // BK for a real pixel, 0 for a padded tap
+    const int8_t* bp[BI];   // this lane's B source for the current step
+    int b_inc[BI];
+  };
+  auto retap = [&](Feed& f, const ConvGeom& gg) {   // ADIR: A pointers of tap (f.r, f.s), channel chunk 0
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int h = f.a_h0[i] + f.r * gg.dil, ww = f.a_w0[i] + f.s * gg.dil;
+      const bool in = f.a_ok[i] && h >= 0 && h < gg.H && ww >= 0 && ww < gg.W;
+      f.ap[i] = in ? f.x + (((int64_t)f.a_n[i] * gg.H + h) * gg.W + ww) * gg.C + hsel * 16 : f.padline;
+      f.a_inc[i] = in ? BK : 0;
+    }
   };
   auto make_feed = [&](Feed& f, const int8_t* __restrict__ xx, const int8_t* __restrict__ ww, const ConvGeom& gg, int zpi,
                        int shf) {
     f.x = xx;
-    f.padline = g_pad_table.b + ((zpi & 0xff) << 4);
+    f.padline = g_pad_table.b + ((zpi & 0xff) << 6);
     f.xorw = shf ? 0x80808080u : 0u;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -311,13 +326,46 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
     f.cc = f.s = f.r = 0;
     f.cchunks = gg.C / BK;
     f.nsteps = gg.R * gg.S * f.cchunks;
+    if (ADIR) {
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {     // KRSC: the reduction index is contiguous, a step is BK bytes further
+        f.bp[i] = f.b_src[i] ? f.b_src[i] + b_seg[i] * 16 : g_pad_table.b;
+        f.b_inc[i] = f.b_src[i] ? BK : 0;
+      }
+      retap(f, gg);
+    }
   };
   i32x4 areg[ADIR ? NBUF : 1][ADIR ? MT : 1][ADIR ? KS : 1];   // ADIR: the A fragments of the steps in flight
   auto issue = [&](Feed& f, const ConvGeom& gg, auto slot_c) {
     constexpr int SL = decltype(slot_c)::value;
     int8_t* base = lds + SL * TILE;
+    if (ADIR) {
+      // B first: its DMA lands in LDS and is awaited by the whole workgroup; the A registers are private
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        if (!(ABL & 16)) __builtin_amdgcn_global_load_lds((gptr_t)f.bp[i], (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
+        f.bp[i] += f.b_inc[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        // explicit global-address-space loads (a generic pointer would become flat_load, which also counts on lgkmcnt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          areg[ADIR ? SL : 0][ADIR ? i : 0][ADIR ? ks : 0] =
+              *reinterpret_cast<const __attribute__((address_space(1))) i32x4*>((gptr_t)(f.ap[i] + ks * 32));
+        f.ap[i] += f.a_inc[i];
+      }
+      if (++f.cc == f.cchunks) {
+        f.cc = 0;
+        if (++f.s == gg.S) {
+          f.s = 0;
+          ++f.r;
+        }
+        retap(f, gg);     // (past the last tap nothing is issued any more; the pointers are simply not used)
+      }
+      return;
+    }
     const int rs = f.r * gg.S + f.s;
-    // B first: its DMA lands in LDS and is awaited by the whole workgroup; the A registers are private
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int8_t* src = f.b_src[i] ? f.b_src[i] + (int64_t)rs * gg.C + f.cc * BK + b_seg[i] * 16 : g_pad_table.b;
@@ -327,16 +375,8 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
     for (int i = 0; i < NA; ++i) {
       const int h = f.a_h0[i] + f.r * gg.dil, ww = f.a_w0[i] + f.s * gg.dil;
       const bool in = f.a_ok[i] && h >= 0 && h < gg.H && ww >= 0 && ww < gg.W;
-      if (ADIR) {
-        const int8_t* src = in ? f.x + (((int64_t)f.a_n[i] * gg.H + h) * gg.W + ww) * gg.C + f.cc * BK + hsel * 16 : f.padline;
-        const int kstride = in ? 32 : 0;          // the pad line is one 16-byte vector, the same for every K chunk
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          areg[ADIR ? SL : 0][ADIR ? i : 0][ADIR ? ks : 0] = *reinterpret_cast<const i32x4*>(src + ks * kstride);
-      } else {
-        const int8_t* src = in ? f.x + (((int64_t)f.a_n[i] * gg.H + h) * gg.W + ww) * gg.C + f.cc * BK + a_seg[i] * 16 : f.padline;
-        if (!(ABL & 8)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
-      }
+      const int8_t* src = in ? f.x + (((int64_t)f.a_n[i] * gg.H + h) * gg.W + ww) * gg.C + f.cc * BK + a_seg[i] * 16 : f.padline;
+      if (!(ABL & 8)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
     }
     if (++f.cc == f.cchunks) {
       f.cc = 0;
@@ -575,7 +615,7 @@ __global__ __launch_bounds__(512) void conv_i8_ws_kernel(const int8_t* __restric
   if (wave >= 4) {
     // ------------------------------------------------------------------ loader waves
     const int lw = wave - 4;
-    const int8_t* padline = g_pad_table.b + ((zpi & 0xff) << 4);
+    const int8_t* padline = g_pad_table.b + ((zpi & 0xff) << 6);
     const int lrow = lane >> 2, pslot = lane & 3;
     int a_n[AI], a_h0[AI], a_w0[AI], a_seg[AI];
     bool a_ok[AI];
@@ -722,7 +762,7 @@ __global__ __launch_bounds__(768) void conv_i8_ws256_kernel(const int8_t* __rest
   if (wave >= 8) {
     // ------------------------------------------------------------------ loader waves
     const int lw = wave - 8;
-    const int8_t* padline = g_pad_table.b + ((zpi & 0xff) << 4);
+    const int8_t* padline = g_pad_table.b + ((zpi & 0xff) << 6);
     const int lrow = lane >> 2, pslot = lane & 3;
     int a_n[AI], a_h0[AI], a_w0[AI], a_seg[AI];
     bool a_ok[AI];
@@ -937,7 +977,7 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
                        int32_t dilation, int32_t x_is_unsigned, dlmcq_stream_t stream, int variant,
                        const ConvEpi& ep = ConvEpi{}, const ConvSeg2* seg2 = nullptr) {
   const bool fused = ep.residual || ep.codes || ep.relu || seg2;
-  if (fused && !(variant == 1 || variant == 2 || variant == 3 || (variant >= 5 && variant <= 8))) return DLMCQ_EINVAL;   // only the LDS-DMA kernel fuses
+  if (fused && !(variant == 1 || variant == 2 || variant == 3 || (variant >= 5 && variant <= 11 && variant != 9))) return DLMCQ_EINVAL;   // only the LDS-DMA kernel fuses
   if (N < 0 || H < 1 || W < 1 || C < 1 || K < 1 || R < 1 || S < 1 || stride < 1 || pad < 0 || dilation < 1)
     return DLMCQ_EINVAL;
   if (C % CV_BK != 0) return DLMCQ_EINVAL;  // the K step is 64 input channels
@@ -1009,6 +1049,10 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
     g.nblk_m = (int)((M + 255) / 256);
     hipLaunchKernelGGL((conv_i8_dma_kernel<256, 128, 3, CV_BK, 0, false, true>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0, st,
                        xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, ConvSeg2{});
+  } else if (variant == 10 && bnn == 128 && C % 128 == 0) {   // 128-byte K steps (half the barriers), A direct
+    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, 128, 0, false, true>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
+  } else if (variant == 11 && bnn == 128 && C % 128 == 0) {   // ... 2 buffers
+    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 2, 128, 0, false, true>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
   } else if (variant == 5) {              // A operand direct to registers, 4-deep ring
     if (bnn == 64) hipLaunchKernelGGL((conv_i8_dma_kernel<128, 64, 4, CV_BK, 0, false, true>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
     else hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 4, CV_BK, 0, false, true>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
@@ -1060,7 +1104,7 @@ extern "C" int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float*
   ep.q_form = q_form;
   const int v = conv_variant();
   return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
-                     x_is_unsigned, stream, ((v >= 1 && v <= 3) || (v >= 5 && v <= 8)) ? v : 1, ep);
+                     x_is_unsigned, stream, ((v >= 1 && v <= 3) || (v >= 5 && v <= 11 && v != 9)) ? v : 1, ep);
 }
 
 extern "C" int dlmcq_conv2d_i8_nhwc_dual(const void* x, const int8_t* w, float* out, const float* bias,
