@@ -237,7 +237,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // fragment bytes (row = lane & 31, 16 bytes of the K step) straight into registers, NBUF - 1 steps ahead; the ring
 // holds the shared B operand (weights) only.
 template <int BM, int BN, int NBUF = 3, int BK = CV_BK, int ABL = 0, bool DUAL = false, bool ADIR = false>
-__global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+__global__ __launch_bounds__(256, (BM == 256 || BN == 256 || DUAL ? 2 : 3)) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                          float* __restrict__ out, const float* __restrict__ bias,
                                                          const int32_t* __restrict__ wsum,
                                                          const float* __restrict__ s_in,
@@ -419,8 +419,16 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
     if (decltype(i)::value < nsteps) issue_next(i);
   });
   constexpr int GROUP = (ADIR ? MT * KS : AI) + BI;   // vector-memory instructions per step per wave
+  // ABL & 64 (timing study, never shipped): lane 0 of wave 0 of the middle workgroup stamps the shader clock at the phase
+  // boundaries of its first 16 steps into the buffer passed as ep.residual
+  unsigned long long* trace = nullptr;
+  if ((ABL & 64) && blockIdx.x == gridDim.x / 2 && tid == 0) trace = (unsigned long long*)ep.residual;
+  auto stamp = [&](int step, int k) {
+    if ((ABL & 64) && trace && step < 16) trace[step * 8 + k] = __builtin_readcyclecounter();
+  };
   auto one_step = [&](int step, auto slot_c) {
     constexpr int U = decltype(slot_c)::value;          // ring slot of this step; step + PF goes to slot (U + PF) % NBUF
+    stamp(step, 0);
     // step's own loads must have landed; the younger groups stay in flight
     if (ABL & (1 | 8 | 16 | 32)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -437,8 +445,11 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: drain (conservative)
     }
+    stamp(step, 1);
     __builtin_amdgcn_s_barrier();                 // everyone's step-k bytes are in LDS; everyone left multiply(k-1)
+    stamp(step, 2);
     if (!(ABL & 1) && step + PF < nsteps) issue_next(std::integral_constant<int, (U + PF) % NBUF>{});  // the slot multiply(k-1) released
+    stamp(step, 3);
     if (DUAL && step == nfirst) {
       // the shortcut pair is complete: dequantise its sum into registers and start the layer's own sum from zero
       const float sin2 = sg.s_in[0];
@@ -492,8 +503,15 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
   };
   for (int s0 = 0; s0 < nsteps; s0 += NBUF)
     static_for<NBUF>([&](auto u) {
-      if (s0 + decltype(u)::value < nsteps) one_step(s0 + decltype(u)::value, u);
+      if (s0 + decltype(u)::value < nsteps) {
+        one_step(s0 + decltype(u)::value, u);
+        if (ABL & 64) {
+          asm volatile("s_nop 0" ::: "memory");
+          stamp(s0 + decltype(u)::value, 4);
+        }
+      }
     });
+  if ((ABL & 64)) { ep.residual = nullptr; }
 
   const float sin = s_in[0];
   const EpiQuant eq(ep);
@@ -578,6 +596,171 @@ __global__ __launch_bounds__(256, (BM == 256 || DUAL ? 2 : 3)) void conv_i8_dma_
         if (out) __builtin_nontemporal_store(v, out + at);
         if (ep.codes) ep.codes[at] = (uint8_t)eq.exact(v);
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Autonomous-wave variant: NO LDS staging of operands and NO barriers.  Every wave owns a 64-row x (NT*32)-column output
+// tile and loads its own A fragments (2 row slabs) and B fragments (NT column slabs) straight from global memory into
+// registers, one K step ahead of the multiplies; the four waves of a workgroup work on four different row tiles of the
+// same columns, so their B loads coincide in the vector L1.  Motivation: in the LDS-ring kernels the
+// DMA, LDS-read and MFMA phases add up instead of overlapping - every variant of them lands at 1.0-1.2 POP/s; here
+// nothing synchronises, waves drift apart and the phases of different waves interleave.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void conv_i8_aw_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                            float* __restrict__ out, const float* __restrict__ bias,
+                                                            const int32_t* __restrict__ wsum, const float* __restrict__ s_in,
+                                                            const float* __restrict__ zp_in, const float* __restrict__ s_w,
+                                                            ConvGeom g, int shift, ConvEpi ep) {
+  constexpr int BK = CV_BK, KS = BK / 32, MT = 2;
+  constexpr int EP_LD = 68;
+  __shared__ __attribute__((aligned(16))) float stage[4 * 32 * EP_LD];   // epilogue transposition only (private per wave)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hsel = lane >> 5;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  const int n0 = blockIdx.y * (NT * 32);
+  if (m0 >= g.M) return;                                   // no barrier anywhere: a wave may simply leave
+  const float zpf = zp_in ? zp_in[0] : 0.0f;
+  const int zpi = (int)__builtin_rintf(zpf);
+  const int8_t* padline = g_pad_table.b + ((zpi & 0xff) << 6);
+  const uint32_t xorw = shift ? 0x80808080u : 0u;
+
+  int a_n[MT], a_h0[MT], a_w0[MT];
+  bool a_ok[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int64_t m = m0 + mi * 32 + (lane & 31);
+    a_ok[mi] = m < g.M;
+    row_origin(g, a_ok[mi] ? (uint32_t)m : 0u, a_n[mi], a_h0[mi], a_w0[mi]);
+  }
+  const int8_t* ap[MT];
+  int a_inc[MT];
+  int t_r = 0, t_s = 0, t_cc = 0;
+  auto retap = [&]() {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int h = a_h0[mi] + t_r * g.dil, ww = a_w0[mi] + t_s * g.dil;
+      const bool in = a_ok[mi] && h >= 0 && h < g.H && ww >= 0 && ww < g.W;
+      ap[mi] = in ? x + (((int64_t)a_n[mi] * g.H + h) * g.W + ww) * g.C + hsel * 16 : padline;
+      a_inc[mi] = in ? BK : 0;
+    }
+  };
+  retap();
+  const int64_t wrow = (int64_t)g.R * g.S * g.C;
+  const int8_t* bp[NT];
+  int b_inc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int k = n0 + j * 32 + (lane & 31);
+    bp[j] = k < g.K ? w + (int64_t)k * wrow + hsel * 16 : g_pad_table.b;     // KRSC: the reduction index is contiguous
+    b_inc[j] = k < g.K ? BK : 0;
+  }
+  const int cchunks = g.C / BK;
+  const int nsteps = g.R * g.S * cchunks;
+
+  typedef const __attribute__((address_space(1))) i32x4* gvec_t;
+  auto fetch = [&](i32x4 (&a)[MT][KS], i32x4 (&b)[KS][NT]) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[mi][ks] = *reinterpret_cast<gvec_t>((gptr_t)(ap[mi] + ks * 32));
+      ap[mi] += a_inc[mi];
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) b[ks][j] = *reinterpret_cast<gvec_t>((gptr_t)(bp[j] + ks * 32));
+      bp[j] += b_inc[j];
+    }
+    if (++t_cc == cchunks) {
+      t_cc = 0;
+      if (++t_s == g.S) {
+        t_s = 0;
+        ++t_r;
+      }
+      retap();
+    }
+  };
+  i32x16 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][j][i] = 0;
+  auto multiply = [&](i32x4 (&a)[MT][KS], i32x4 (&b)[KS][NT]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      i32x4 af[MT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+        af[mi] = i32x4{(int)(a[mi][ks].x ^ xorw), (int)(a[mi][ks].y ^ xorw), (int)(a[mi][ks].z ^ xorw), (int)(a[mi][ks].w ^ xorw)};
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) acc[mi][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[mi], b[ks][j], acc[mi][j], 0, 0, 0);
+    }
+  };
+  i32x4 a0[MT][KS], b0[KS][NT], a1[MT][KS], b1[KS][NT];
+  fetch(a0, b0);
+  for (int step = 0; step < nsteps; step += 2) {
+    if (step + 1 < nsteps) fetch(a1, b1);
+    multiply(a0, b0);
+    if (step + 1 < nsteps) {
+      if (step + 2 < nsteps) fetch(a0, b0);
+      multiply(a1, b1);
+    }
+  }
+
+  // ---- epilogue: as in the LDS-ring kernel, 32 rows x 64 columns at a time through this wave's private stage ----
+  const float sin = s_in[0];
+  const EpiQuant eq(ep);
+  float* stg = stage + wave * (32 * EP_LD);
+  const int er = lane >> 4, ec = (lane & 15) * 4;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+    for (int h = 0; h < NT / 2 + (NT & 1); ++h) {
+      f32x4 idt[8];
+      const int colv = n0 + h * 64 + ec;
+      if (ep.residual) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int64_t row = m0 + mi * 32 + it * 4 + er;
+          idt[it] = (row < g.M && colv + 3 < g.K) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ep.residual + row * g.K + colv))
+                                                  : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = h * 2 + jj;
+        if (j >= NT) continue;
+        const int col = n0 + j * 32 + (lane & 31);
+        const bool cok = col < g.K;
+        const float mult = cok ? sin * s_w[col] : 0.0f;
+        const int corr = cok ? (shift - zpi) * wsum[col] : 0;
+        const float bv = (cok && bias) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = (i & 3) + 8 * (i >> 2) + 4 * hsel;
+          stg[r * EP_LD + jj * 32 + (lane & 31)] = (float)(acc[mi][j][i] + corr) * mult + bv;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = it * 4 + er;
+        const int64_t row = m0 + mi * 32 + r;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * EP_LD + ec);
+        if (row < g.M && colv + 3 < g.K) {
+          const int64_t at = row * g.K + colv;
+          if (ep.residual) v = f32x4{v.x + idt[it].x, v.y + idt[it].y, v.z + idt[it].z, v.w + idt[it].w};
+          if (ep.relu) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
+          if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
+          if (ep.codes) __builtin_nontemporal_store(eq.code4(v), reinterpret_cast<uint32_t*>(ep.codes + at));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
 }
 
@@ -977,7 +1160,8 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
                        int32_t dilation, int32_t x_is_unsigned, dlmcq_stream_t stream, int variant,
                        const ConvEpi& ep = ConvEpi{}, const ConvSeg2* seg2 = nullptr) {
   const bool fused = ep.residual || ep.codes || ep.relu || seg2;
-  if (fused && !(variant == 1 || variant == 2 || variant == 3 || (variant >= 5 && variant <= 11 && variant != 9))) return DLMCQ_EINVAL;   // only the LDS-DMA kernel fuses
+  const bool fused_dual = seg2 != nullptr;
+  if (fused && !(variant == 1 || variant == 2 || variant == 3 || (variant >= 5 && variant <= 15 && variant != 9))) return DLMCQ_EINVAL;   // only the LDS-DMA kernel fuses
   if (N < 0 || H < 1 || W < 1 || C < 1 || K < 1 || R < 1 || S < 1 || stride < 1 || pad < 0 || dilation < 1)
     return DLMCQ_EINVAL;
   if (C % CV_BK != 0) return DLMCQ_EINVAL;  // the K step is 64 input channels
@@ -1049,6 +1233,24 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
     g.nblk_m = (int)((M + 255) / 256);
     hipLaunchKernelGGL((conv_i8_dma_kernel<256, 128, 3, CV_BK, 0, false, true>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0, st,
                        xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, ConvSeg2{});
+  } else if ((variant == 15 || (variant == 1 && K >= 512 && M <= 32768 && !fused_dual)) && K % 256 == 0) {   // 128 x 256 tiles, A direct: a third fewer
+    // operand bytes per MAC; pays where the grid is small anyway (the 7x7 stage: +10-17 %), loses tiles elsewhere
+    g.nblk_n = (int)(K / 256);
+    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 256, 3, CV_BK, 0, false, true>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0, st,
+                       xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, ConvSeg2{});
+  } else if (variant == 13 && bnn == 128) {   // timing study
+    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 64, false, true>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
+  } else if (variant == 14 && bnn == 128) {
+    hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 64, false, false>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
+  } else if (variant == 12 && (K & 3) == 0) {     // autonomous waves: no LDS operands, no barriers
+    const int64_t mt = (M + 255) / 256;
+    if (K % 128 == 0 || K > 96) {
+      hipLaunchKernelGGL((conv_i8_aw_kernel<4>), dim3((uint32_t)mt, (uint32_t)((K + 127) / 128)), dim3(256), 0, st, xs, w, out, bias, wsum,
+                         in_scale, in_zero_point, w_scale, g, shift, ep);
+    } else {
+      hipLaunchKernelGGL((conv_i8_aw_kernel<2>), dim3((uint32_t)mt, (uint32_t)((K + 63) / 64)), dim3(256), 0, st, xs, w, out, bias, wsum,
+                         in_scale, in_zero_point, w_scale, g, shift, ep);
+    }
   } else if (variant == 10 && bnn == 128 && C % 128 == 0) {   // 128-byte K steps (half the barriers), A direct
     hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, 128, 0, false, true>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
   } else if (variant == 11 && bnn == 128 && C % 128 == 0) {   // ... 2 buffers
@@ -1104,7 +1306,7 @@ extern "C" int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float*
   ep.q_form = q_form;
   const int v = conv_variant();
   return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
-                     x_is_unsigned, stream, ((v >= 1 && v <= 3) || (v >= 5 && v <= 11 && v != 9)) ? v : 1, ep);
+                     x_is_unsigned, stream, ((v >= 1 && v <= 3) || (v >= 5 && v <= 15 && v != 9)) ? v : 1, ep);
 }
 
 extern "C" int dlmcq_conv2d_i8_nhwc_dual(const void* x, const int8_t* w, float* out, const float* bias,
@@ -1152,6 +1354,19 @@ extern "C" int dlmcq_conv2d_i8_nhwc_dual(const void* x, const int8_t* w, float* 
   const int v = conv_variant();
   return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
                      x_is_unsigned, stream, v == 2 ? 2 : 1, ep, &s2);
+}
+
+// NOT part of the ABI: timing study - variants 13 (A direct) / 14 (A through LDS) stamp the shader clock at the phase
+// boundaries of one wave's first 16 K steps into `trace` (16 x 8 uint64).
+extern "C" int dlmcq_x_conv2d_i8_trace(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                                       const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N,
+                                       int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride,
+                                       int32_t pad, int32_t dilation, int32_t x_is_unsigned, dlmcq_stream_t stream,
+                                       int32_t variant, void* trace) {
+  ConvEpi ep{};
+  ep.residual = static_cast<const float*>(trace);
+  return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
+                     x_is_unsigned, stream, variant, ep);
 }
 
 // NOT part of the ABI (absent from include/dlmcq.h): the same call with an explicit kernel variant, for the tests and

@@ -28,7 +28,7 @@ CASES = [  # N, C, H, W, K, R, stride, pad, dil
 CASES_BIG = [(2, 64, 260, 260, 128, 3, 1, 1, 1)]   # M = 135 200 rows: reaches the 256-row tiles of variant 3
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15])
 def test_conv_i8_kernel_variants(variant):
     """Every kernel variant (0 register-staged, 1 default dispatch, 2 LDS-DMA 128-row only, 3 256-row tiles,
     4 wave-specialised 128-row, 9 wave-specialised 256-row forced) on every shape."""
