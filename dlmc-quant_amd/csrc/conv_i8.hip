@@ -237,7 +237,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // fragment bytes (row = lane & 31, 16 bytes of the K step) straight into registers, NBUF - 1 steps ahead; the ring
 // holds the shared B operand (weights) only.
 template <int BM, int BN, int NBUF = 3, int BK = CV_BK, int ABL = 0, bool DUAL = false, bool ADIR = false>
-__global__ __launch_bounds__(256, (BM == 256 || BN == 256 || DUAL ? 2 : 3)) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+__global__ __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : (BM == 256 || BN == 256 || DUAL ? 2 : 3))) void conv_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                          float* __restrict__ out, const float* __restrict__ bias,
                                                          const int32_t* __restrict__ wsum,
                                                          const float* __restrict__ s_in,
@@ -448,7 +448,8 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256 || DUAL ? 2 : 3)) void
     stamp(step, 1);
     __builtin_amdgcn_s_barrier();                 // everyone's step-k bytes are in LDS; everyone left multiply(k-1)
     stamp(step, 2);
-    if (!(ABL & 1) && step + PF < nsteps) issue_next(std::integral_constant<int, (U + PF) % NBUF>{});  // the slot multiply(k-1) released
+    constexpr bool LATE = BM * BN >= 256 * 256;   // one wave per SIMD: issue the loads BEHIND the MFMAs (they execute meanwhile)
+    if (!LATE && !(ABL & 1) && step + PF < nsteps) issue_next(std::integral_constant<int, (U + PF) % NBUF>{});  // the slot multiply(k-1) released
     stamp(step, 3);
     if (DUAL && step == nfirst) {
       // the shortcut pair is complete: dequantise its sum into registers and start the layer's own sum from zero
@@ -500,6 +501,10 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256 || DUAL ? 2 : 3)) void
         }
       }
     }
+    if (LATE) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ABL & 1) && step + PF < nsteps) issue_next(std::integral_constant<int, (U + PF) % NBUF>{});
+    }
   };
   for (int s0 = 0; s0 < nsteps; s0 += NBUF)
     static_for<NBUF>([&](auto u) {
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256 || DUAL ? 2 : 3)) void
   const float sin = s_in[0];
   const EpiQuant eq(ep);
   constexpr bool EP_FITS = EP_BYTES <= LDS_BYTES;   // the LDS epilogue stage re-uses the operand buffers
-  if (MT == 1 && EP_FITS && (g.K & 3) == 0) {
+  if (EP_FITS && (g.K & 3) == 0) {
     // ---- epilogue through LDS: accumulator layout (lane = channel, register = row) -> row-major, so that each
     // lane stores 16 B and each wave-instruction writes 4 rows x 256 contiguous bytes: 16 dwordx4 stores per lane
     // instead of 64 dword stores (the 1x1 layers are bound by this output stream).  Two passes of 64 channels. ----
@@ -524,23 +529,24 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256 || DUAL ? 2 : 3)) void
     __builtin_amdgcn_s_barrier();                   // every wave is done reading the operand buffers
     float* stg = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
     const int er = lane >> 4, ec = (lane & 15) * 4;
-#pragma unroll
-    for (int h = 0; h < NT / 2 + (NT & 1); ++h) {
+    constexpr int NH = NT / 2 + (NT & 1);
+    static_for<MT * NH>([&](auto pass_c) {    // (compile-time indices: the accumulators must stay in registers)
+      constexpr int mi = decltype(pass_c)::value / NH, h = decltype(pass_c)::value % NH;
       // the shortcut tile is requested first: its latency hides behind the dequantise-and-stage phase below
       f32x4 idt[8];
       if (ep.residual) {
         const int colr = n0 + h * 64 + ec;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-          const int64_t row = m0 + wrow0 + it * 4 + er;
+          const int64_t row = m0 + wrow0 + mi * 32 + it * 4 + er;
           idt[it] = (row < g.M && colr < g.K) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ep.residual + row * g.K + colr))
                                               : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
       }
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = h * 2 + jj;
-        if (j >= NT) continue;
+      static_for<2>([&](auto jj_c) {
+        constexpr int jj = decltype(jj_c)::value;
+        constexpr int j = h * 2 + jj < NT ? h * 2 + jj : NT - 1;
+        if (h * 2 + jj >= NT) return;
         const int col = n0 + j * 32 + (lane & 31);
         const bool cok = col < g.K;
         const float mult = cok ? sin * s_w[col] : 0.0f;
@@ -549,18 +555,18 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256 || DUAL ? 2 : 3)) void
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-          float v = (float)(acc[0][j][i] + corr) * mult + bv;
-          if (DUAL) v = v + extra[0][DUAL ? j : 0][i];
+          float v = (float)(acc[mi][j][i] + corr) * mult + bv;
+          if (DUAL) v = v + extra[DUAL ? mi : 0][DUAL ? j : 0][i];
           stg[r * EP_LD + jj * 32 + (lane & 31)] = v;
         }
-      }
+      });
       // a wave only reads back what it wrote itself: no block barrier, just the LDS counter
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const int col = n0 + h * 64 + ec;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int r = it * 4 + er;
-        const int64_t row = m0 + wrow0 + r;
+        const int64_t row = m0 + wrow0 + mi * 32 + r;
         f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * EP_LD + ec);
         if (row < g.M && col < g.K) {
           const int64_t at = row * g.K + col;
@@ -572,9 +578,10 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256 || DUAL ? 2 : 3)) void
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the stage
-    }
+    });
     return;
   }
+  if constexpr (BM * BN < 256 * 256) {   // (the largest tile is only launched where the staged epilogue applies)
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + j * 32 + (lane & 31);
@@ -596,6 +603,7 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256 || DUAL ? 2 : 3)) void
         if (out) __builtin_nontemporal_store(v, out + at);
         if (ep.codes) ep.codes[at] = (uint8_t)eq.exact(v);
       }
+  }
   }
 }
 
@@ -1161,7 +1169,7 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
                        const ConvEpi& ep = ConvEpi{}, const ConvSeg2* seg2 = nullptr) {
   const bool fused = ep.residual || ep.codes || ep.relu || seg2;
   const bool fused_dual = seg2 != nullptr;
-  if (fused && !(variant == 1 || variant == 2 || variant == 3 || (variant >= 5 && variant <= 15 && variant != 9))) return DLMCQ_EINVAL;   // only the LDS-DMA kernel fuses
+  if (fused && !(variant == 1 || variant == 2 || variant == 3 || (variant >= 5 && variant <= 17 && variant != 9))) return DLMCQ_EINVAL;   // only the LDS-DMA kernel fuses
   if (N < 0 || H < 1 || W < 1 || C < 1 || K < 1 || R < 1 || S < 1 || stride < 1 || pad < 0 || dilation < 1)
     return DLMCQ_EINVAL;
   if (C % CV_BK != 0) return DLMCQ_EINVAL;  // the K step is 64 input channels
@@ -1238,6 +1246,16 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
     g.nblk_n = (int)(K / 256);
     hipLaunchKernelGGL((conv_i8_dma_kernel<128, 256, 3, CV_BK, 0, false, true>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0, st,
                        xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, ConvSeg2{});
+  } else if (variant == 16 && K % 256 == 0) {   // 256 x 256 tiles, one workgroup per CU: 4x fewer operand bytes per MAC
+    g.nblk_m = (int)((M + 255) / 256);
+    g.nblk_n = (int)(K / 256);
+    hipLaunchKernelGGL((conv_i8_dma_kernel<256, 256, 3, CV_BK, 0, false, false>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0, st,
+                       xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, ConvSeg2{});
+  } else if (variant == 17 && K % 256 == 0) {   // ... with the A operand direct to registers
+    g.nblk_m = (int)((M + 255) / 256);
+    g.nblk_n = (int)(K / 256);
+    hipLaunchKernelGGL((conv_i8_dma_kernel<256, 256, 3, CV_BK, 0, false, true>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0, st,
+                       xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, ConvSeg2{});
   } else if (variant == 13 && bnn == 128) {   // timing study
     hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 64, false, true>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
   } else if (variant == 14 && bnn == 128) {
@@ -1306,7 +1324,7 @@ extern "C" int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float*
   ep.q_form = q_form;
   const int v = conv_variant();
   return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
-                     x_is_unsigned, stream, ((v >= 1 && v <= 3) || (v >= 5 && v <= 15 && v != 9)) ? v : 1, ep);
+                     x_is_unsigned, stream, ((v >= 1 && v <= 3) || (v >= 5 && v <= 17 && v != 9)) ? v : 1, ep);
 }
 
 extern "C" int dlmcq_conv2d_i8_nhwc_dual(const void* x, const int8_t* w, float* out, const float* bias,

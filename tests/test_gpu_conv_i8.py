@@ -28,12 +28,12 @@ CASES = [  # N, C, H, W, K, R, stride, pad, dil
 CASES_BIG = [(2, 64, 260, 260, 128, 3, 1, 1, 1)]   # M = 135 200 rows: reaches the 256-row tiles of variant 3
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 16, 17])
 def test_conv_i8_kernel_variants(variant):
     """Every kernel variant (0 register-staged, 1 default dispatch, 2 LDS-DMA 128-row only, 3 256-row tiles,
     4 wave-specialised 128-row, 9 wave-specialised 256-row forced) on every shape."""
     from dlmc.quantization.scalar import kernels as K
-    for idx, (n, c, h, w, k, r, stride, pad, dil) in enumerate(CASES + (CASES_BIG if variant in (1, 3, 8, 9) else [])):
+    for idx, (n, c, h, w, k, r, stride, pad, dil) in enumerate(CASES + (CASES_BIG if variant in (1, 3, 8, 9, 16, 17) else [])):
         g = gen(idx)
         codes = torch.randint(0, 256, (n, c, h, w), generator=g).to(torch.uint8)
         wt = torch.randn(k, c, r, r, generator=g) * 0.05
