@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : (BM == 256 || BN =
     stamp(step, 1);
     __builtin_amdgcn_s_barrier();                 // everyone's step-k bytes are in LDS; everyone left multiply(k-1)
     stamp(step, 2);
-    constexpr bool LATE = BM * BN >= 256 * 256;   // one wave per SIMD: issue the loads BEHIND the MFMAs (they execute meanwhile)
+    constexpr bool LATE = BM * BN >= 256 * 256 && !(ABL & 64);   // one wave per SIMD: issue the loads BEHIND the MFMAs (they execute meanwhile)
     if (!LATE && !(ABL & 1) && step + PF < nsteps) issue_next(std::integral_constant<int, (U + PF) % NBUF>{});  // the slot multiply(k-1) released
     stamp(step, 3);
     if (DUAL && step == nfirst) {
@@ -1169,7 +1169,7 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
                        const ConvEpi& ep = ConvEpi{}, const ConvSeg2* seg2 = nullptr) {
   const bool fused = ep.residual || ep.codes || ep.relu || seg2;
   const bool fused_dual = seg2 != nullptr;
-  if (fused && !(variant == 1 || variant == 2 || variant == 3 || (variant >= 5 && variant <= 17 && variant != 9))) return DLMCQ_EINVAL;   // only the LDS-DMA kernel fuses
+  if (fused && !(variant == 1 || variant == 2 || variant == 3 || (variant >= 5 && variant <= 18 && variant != 9))) return DLMCQ_EINVAL;   // only the LDS-DMA kernel fuses
   if (N < 0 || H < 1 || W < 1 || C < 1 || K < 1 || R < 1 || S < 1 || stride < 1 || pad < 0 || dilation < 1)
     return DLMCQ_EINVAL;
   if (C % CV_BK != 0) return DLMCQ_EINVAL;  // the K step is 64 input channels
@@ -1255,6 +1255,11 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
     g.nblk_m = (int)((M + 255) / 256);
     g.nblk_n = (int)(K / 256);
     hipLaunchKernelGGL((conv_i8_dma_kernel<256, 256, 3, CV_BK, 0, false, true>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0, st,
+                       xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, ConvSeg2{});
+  } else if (variant == 18 && K % 256 == 0) {   // timing study of the 256 x 256 tile
+    g.nblk_m = (int)((M + 255) / 256);
+    g.nblk_n = (int)(K / 256);
+    hipLaunchKernelGGL((conv_i8_dma_kernel<256, 256, 3, CV_BK, 64, false, false>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0, st,
                        xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, ConvSeg2{});
   } else if (variant == 13 && bnn == 128) {   // timing study
     hipLaunchKernelGGL((conv_i8_dma_kernel<128, 128, 3, CV_BK, 64, false, true>), DLMCQ_CONV_ARGS, ep, ConvSeg2{});
