@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : (BM == 256 || BN =
     for (int i = 0; i < NA; ++i) {
       const int h = f.a_h0[i] + f.r * gg.dil, ww = f.a_w0[i] + f.s * gg.dil;
       const bool in = f.a_ok[i] && h >= 0 && h < gg.H && ww >= 0 && ww < gg.W;
-      f.ap[i] = in ? f.x + (((int64_t)f.a_n[i] * gg.H + h) * gg.W + ww) * gg.C + hsel * 16 : f.padline;
+      f.ap[i] = in ? f.x + (((int64_t)f.a_n[i] * gg.H + h) * gg.W + ww) * gg.C + (ADIR ? hsel : a_seg[ADIR ? 0 : i]) * 16 : f.padline;
       f.a_inc[i] = in ? BK : 0;
     }
   };
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : (BM == 256 || BN =
     f.cc = f.s = f.r = 0;
     f.cchunks = gg.C / BK;
     f.nsteps = gg.R * gg.S * f.cchunks;
-    if (ADIR) {
+    if (ADIR || BM * BN >= 256 * 256) {
 #pragma unroll
       for (int i = 0; i < BI; ++i) {     // KRSC: the reduction index is contiguous, a step is BK bytes further
         f.bp[i] = f.b_src[i] ? f.b_src[i] + b_seg[i] * 16 : g_pad_table.b;
@@ -378,12 +378,20 @@ __global__ __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : (BM == 256 || BN =
       const int8_t* src = in ? f.x + (((int64_t)f.a_n[i] * gg.H + h) * gg.W + ww) * gg.C + f.cc * BK + a_seg[i] * 16 : f.padline;
       if (!(ABL & 8)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
     }
+    constexpr bool BIG = BM * BN >= 256 * 256;   // keeps the running pointers of the pinned steady state in step
+    if (BIG) {
+#pragma unroll
+      for (int i = 0; i < BI; ++i) f.bp[i] += f.b_inc[i];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) f.ap[i] += f.a_inc[i];
+    }
     if (++f.cc == f.cchunks) {
       f.cc = 0;
       if (++f.s == gg.S) {
         f.s = 0;
         ++f.r;
       }
+      if (BIG) retap(f, gg);
     }
   };
 
@@ -506,7 +514,85 @@ __global__ __launch_bounds__(256, (BM * BN >= 256 * 256 ? 1 : (BM == 256 || BN =
       if (!(ABL & 1) && step + PF < nsteps) issue_next(std::integral_constant<int, (U + PF) % NBUF>{});
     }
   };
-  for (int s0 = 0; s0 < nsteps; s0 += NBUF)
+  // Largest tile (one wave per SIMD): steady-state steps as ONE scheduling region each, with the instruction stream
+  // pinned so that the operand loads and the second K chunk's fragment reads sit in the shadow of the MFMAs (a wave
+  // that is stuck issuing a load cannot issue MFMAs: back to back the 8 loads cost 184 clocks each, spaced out ~60)
+  int s_first = 0;
+  if constexpr (BM * BN >= 256 * 256 && !ADIR && !DUAL && !(ABL & ~64) && MT == 2 && NT == 8 && KS == 2) {
+    // one operand load of the step being fetched (pieces 0..BI-1: weights, BI..BI+AI-1: activations)
+    auto issue_piece = [&](Feed& f, const ConvGeom& gg, auto slot_c, auto piece_c) {
+      constexpr int SL = decltype(slot_c)::value, PC = decltype(piece_c)::value;
+      int8_t* base = lds + SL * TILE;
+      if constexpr (PC < BI) {
+        __builtin_amdgcn_global_load_lds((gptr_t)f.bp[PC], (lptr_t)(base + TILE_A + (PC * 4 + wave) * 1024), 16, 0, 0);
+        f.bp[PC] += f.b_inc[PC];
+      } else {
+        constexpr int i = PC - BI;
+        __builtin_amdgcn_global_load_lds((gptr_t)f.ap[i], (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
+        f.ap[i] += f.a_inc[i];
+      }
+    };
+    auto steady = [&](auto slot_c) {
+      constexpr int U = decltype(slot_c)::value;
+      constexpr int KEEP = (PF - 1) * GROUP;
+      static_assert(KEEP == 8 && AI + BI == 8, "vmcnt immediate / piece count");
+      const int tstep = issued - PF;
+      stamp(tstep, 0);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      stamp(tstep, 1);
+      __builtin_amdgcn_s_barrier();
+      stamp(tstep, 2);
+      const int8_t* base = lds + U * TILE;
+      auto afrag = [&](int ks, int mi) {
+        const int arow = wrow0 + mi * 32 + (lane & 31);
+        const i32x4 t = *reinterpret_cast<const i32x4*>(base + arow * BK + (((ks * 2 + hsel) ^ ((arow / RPB) & (SLOTS - 1))) << 4));
+        return i32x4{(int)(t.x ^ fm.xorw), (int)(t.y ^ fm.xorw), (int)(t.z ^ fm.xorw), (int)(t.w ^ fm.xorw)};
+      };
+      auto bfrag = [&](int ks, int j) {
+        const int brow = j * 32 + (lane & 31);
+        return *reinterpret_cast<const i32x4*>(base + TILE_A + brow * BK + (((ks * 2 + hsel) ^ ((brow / RPB) & (SLOTS - 1))) << 4));
+      };
+      i32x4 a0[MT], b0[NT], a1[MT], b1[NT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) a0[mi] = afrag(0, mi);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b0[j] = bfrag(0, j);
+      __builtin_amdgcn_sched_barrier(0);
+      // 8 groups: two MFMAs of the first K chunk, ONE operand load of step k+2, one or two fragment reads of the second
+      static_for<8>([&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) acc[mi][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[mi], b0[i], acc[mi][i], 0, 0, 0);
+        issue_piece(fm, g, std::integral_constant<int, (U + PF) % NBUF>{}, i_c);
+        if constexpr (i == 0) {
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) a1[mi] = afrag(1, mi);
+        }
+        b1[i] = bfrag(1, i);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      stamp(tstep, 3);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) acc[mi][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[mi], b1[j], acc[mi][j], 0, 0, 0);
+      if (ABL & 64) {
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(tstep, 4);
+      }
+      ++issued;
+      if (++fm.cc == fm.cchunks) {
+        fm.cc = 0;
+        if (++fm.s == g.S) {
+          fm.s = 0;
+          ++fm.r;
+        }
+        retap(fm, g);
+      }
+    };
+    for (; s_first + NBUF + PF <= nsteps; s_first += NBUF) static_for<NBUF>(steady);
+  }
+  for (int s0 = s_first; s0 < nsteps; s0 += NBUF)
     static_for<NBUF>([&](auto u) {
       if (s0 + decltype(u)::value < nsteps) {
         one_step(s0 + decltype(u)::value, u);
