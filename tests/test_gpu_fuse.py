@@ -148,7 +148,7 @@ QBASE = {"weight": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 
 
 @pytest.mark.parametrize("arch,qtype,cfg,res,signed_image", [
     ("resnet50", "FSPTQ", FSPTQ, 64, False), ("resnet18", "FSPTQ", FSPTQ, 96, True), ("repvgg_a1", "FSPTQ", FSPTQ, 64, False),
-    ("resnet18", None, QBASE, 64, True), ("mobileone_s1", "FSPTQ", FSPTQ, 64, False)])
+    ("resnet18", None, QBASE, 64, True), ("mobileone_s1", "FSPTQ", FSPTQ, 64, False), ("resnet18-bn", "FSPTQ", FSPTQ, 64, False)])
 def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res, signed_image):
     """`signed_image`: N(0,1) pixels.  Under the FSPTQ u8 activation config the reference's zero point is then the
     (negative, non-integer) minimum (FSPTQuant/base.py:99-103 via ops.py:20-34), the first layer's codes are not
@@ -158,12 +158,15 @@ def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res, sign
     from dlmc.utils.merge_bn import merge_bn
     from dlmc.utils.quantize import quantize_model
     torch.manual_seed(2333)
+    keep_bn = arch.endswith("-bn")                # BatchNorm left in place: nothing may be folded across it
+    arch = arch.split("-")[0]
     net = W.MODELS[arch]().to(DEV).eval()
     for m in net.modules():                       # non-trivial BN statistics, then fold them as FSPTQuant.py:67 does
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.normal_(0, 0.1)
             m.running_var.uniform_(0.5, 1.5)
-    net = merge_bn(net, inplace=True)
+    if not keep_bn:
+        net = merge_bn(net, inplace=True)
     quantize_model(net, cfg, None, qtype, int8_gemm=True)
     x = torch.randn(4, 3, res, res, device=DEV)
     if not signed_image:
@@ -185,7 +188,9 @@ def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res, sign
     if arch == "repvgg_a1":
         assert rep.layers == 23 and rep.relu == 22 and rep.stem == 1 and rep.skipped == []
         assert rep.fp32_outputs == 2    # the last block (feeds the pool) and the classifier
-    if arch == "resnet18" and qtype == "FSPTQ":
+    if keep_bn:
+        assert rep.relu == 0 and rep.residual == 0 and rep.emit == 0 and rep.layers == 21
+    elif arch == "resnet18" and qtype == "FSPTQ":
         assert rep.stem == 0 and rep.skipped == ["conv1"]       # non-integer zero point: fp32 first layer
     if arch == "resnet18" and qtype is None:
         assert rep.stem == 1 and rep.pooled == 0                # QBase: signed codes, zero offset; this pool also feeds a shortcut
