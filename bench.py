@@ -248,6 +248,30 @@ def main():
         main_roof["traffic"], src = pmc_traffic("conv_i8_dma_kernel")
         if src:
             main_roof["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
+    if args.fused:
+        # In the fused plan the activation quantiser lives in the conv epilogue, so the stand-alone fake-quant kernel
+        # hardly appears in the step.  Its own roofline is measured here, live, on BASELINE configs[1]'s tensor
+        # (A = 64 x 256 x 56 x 56 fp32, per-channel axis 1: 8 algorithmic bytes per element), HIP events per launch.
+        from dlmc import _native as Nn
+        a = torch.randn(64, 256, 56, 56, device=dev)
+        sc = a.abs().amax(dim=(0, 2, 3)) / 127 + 1e-6
+        zs = torch.zeros_like(sc)
+        for _ in range(3):
+            K.fake_quant(a, sc, zs, -127, 127, Nn.FORM_EMULATE, ch_axis=1)
+        K.PROFILE.enabled = True
+        K.PROFILE.reset()
+        for _ in range(20):
+            K.fake_quant(a, sc, zs, -127, 127, Nn.FORM_EMULATE, ch_axis=1)
+        torch.cuda.synchronize()
+        K.PROFILE.enabled = False
+        f2 = {"launches": 0, "bytes": 0, "ms": 0.0}
+        for tag, nbytes, e0, e1 in K.PROFILE.records:
+            f2["launches"] += 1
+            f2["bytes"] += nbytes
+            f2["ms"] += e0.elapsed_time(e1)
+        fq_roof = roof("fq_channel", f2, "fq_channel_kernel<EMULATE> stand-alone on BASELINE configs[1] (64x256x56x56 fp32, per-channel "
+                                         "axis 1, 4 B read + 4 B written per element); in the fused plan this arithmetic runs in the conv epilogue")
+        del a
     qbytes = sum(f["bytes"] for k, f in fam.items() if k.startswith("fq"))
     qms = sum(f["ms"] for k, f in fam.items() if k.startswith("fq"))
     out = {
