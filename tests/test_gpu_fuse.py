@@ -282,6 +282,29 @@ def test_maxpool_on_codes_equals_quantised_maxpool(dtype):
     same(K.maxpool_codes(b, 3, 2, 1), a, "commutation")
 
 
+def test_streamed_plan_is_bit_identical_and_refuses_qbase():
+    import workloads as W
+    from dlmc.utils.fuse import StreamedPlan, fuse_inference
+    from dlmc.utils.merge_bn import merge_bn
+    from dlmc.utils.quantize import quantize_model
+    torch.manual_seed(2333)
+    net = merge_bn(W.resnet18().to(DEV).eval(), inplace=True)
+    quantize_model(net, FSPTQ, None, "FSPTQ", int8_gemm=True)
+    x = torch.relu(torch.randn(6, 3, 64, 64, device=DEV))
+    with torch.no_grad():
+        net(x)
+        plan = fuse_inference(net)
+        want = plan(x * 0.7)
+        for n in (1, 2, 3, 8):          # 8 > batch: falls back to one stream
+            same(StreamedPlan(plan, n)(x * 0.7), want, f"{n} streams")
+    q = W.resnet18().to(DEV).eval()
+    quantize_model(q, QBASE, None, None, int8_gemm=True)
+    with torch.no_grad():
+        q(x)
+    with pytest.raises(ValueError):
+        StreamedPlan(fuse_inference(q), 2)
+
+
 def test_fuse_requires_a_calibrated_eval_model():
     import workloads as W
     from dlmc.utils.fuse import fuse_inference
