@@ -1248,6 +1248,18 @@ static int conv_variant() {
   return v;
 }
 
+// Kernel variants (DLMCQ_CONV_VARIANT / dlmcq_x_conv2d_i8_variant; everything but 1 exists for A/B measurements and tests):
+//    1  default dispatch: 128x128 (or 128x64) tiles, weights through a 3-deep LDS-DMA ring, activations straight to
+//       registers (ADIR) - except 1x1 reductions into <= 64 channels, which keep both operands in the ring; 128x256
+//       tiles on grids of <= 32768 rows with >= 512 output channels; the DUAL kernel when a second operand pair is given
+//    0  register-staged 2-buffer kernel (the first version)            2  LDS-DMA ring for both operands (no ADIR)
+//    3  256-row tiles where eligible                                   4  wave-specialised 128-row (loader + MFMA waves)
+//    5 / 6 / 7  ADIR with a 4- / 3- / 5-deep ring                      8  256x128 ADIR
+//    9  wave-specialised 256-row tiles (12 waves)                      10 / 11  ADIR with 128-byte K steps, 3 / 2 buffers
+//   12  autonomous waves: no LDS operands, no barriers                 15  128x256 ADIR
+//   16 / 17  256x256 tiles, one workgroup per CU (16: pinned instruction stream in the steady state; 17: ADIR)
+//   13 / 14 / 18  timing-study builds (phase stamps; tools/conv_trace.py) of 6 / 2 / 16
+// What each taught is in DESIGN.md 5.1.
 static int conv_launch(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
                        const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N, int64_t H,
                        int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
