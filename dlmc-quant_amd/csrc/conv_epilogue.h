@@ -25,13 +25,13 @@ struct ConvEpi {
 
 struct EpiQuant {   // the consumer's constants, resolved once per thread
   float dv, rdv, of, zadd, lo, hi;
+  int form;
   bool sgn;
   __device__ __forceinline__ EpiQuant(const ConvEpi& ep)
-      : dv(1.0f), rdv(1.0f), of(0.0f), zadd(0.0f), lo(ep.q_lo), hi(ep.q_hi), sgn(ep.q_lo < 0.0f) {
+      : dv(1.0f), rdv(1.0f), of(0.0f), zadd(0.0f), lo(ep.q_lo), hi(ep.q_hi), form(ep.q_form), sgn(ep.q_lo < 0.0f) {
     if (!ep.codes) return;
     const float s = ep.q_scale[0];
     const float z = ep.q_zp ? ep.q_zp[0] : 0.0f;
-    const int form = ep.q_form;
     dv = form == DLMCQ_FORM_EMULATE ? s + 1e-7f : (form == DLMCQ_FORM_QBASE ? ste_scale(s, ep.q_g) : s);
     // EMULATE / QBASE divide (v - offset); ZEROPOINT adds the zero point after rounding; v - 0 is v, r + 0 is r
     of = (form == DLMCQ_FORM_EMULATE || form == DLMCQ_FORM_QBASE) ? z : 0.0f;
@@ -41,13 +41,19 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
     const bool tame = __builtin_fabsf(dv) >= 0x1p-100f && __builtin_fabsf(dv) <= 0x1p100f && __builtin_fabsf(zadd) <= 256.0f;
     rdv = tame ? 1.0f / dv : __builtin_nanf("");
   }
-  // All four forms reduce to  code = clamp(rint(d) + zadd, lo, hi)  with d = fl(u / dv), u = v - of
-  // (rint(clamp(d)) = clamp(rint(d)) for integral bounds, and the STE identity (r - d) + d returns r exactly;
-  //  a NaN becomes code 0, as code_of does it in the stand-alone kernels).
+  // the reference arithmetic itself, form by form (fq_one): what the fast path below must reproduce, and what decides
+  // the elements it cannot vouch for.  (Not interchangeable with the reduced formula for +-inf: the STE identity
+  // R(v) = (rint(v) - v) + v turns an infinite quotient into NaN -> code 0, where EMULATE's plain rint saturates.)
   __device__ __forceinline__ uint32_t exact(float v) const {
-    const float q = clamp_nan(__builtin_rintf((v - of) / dv) + zadd, lo, hi);
+    float q;
+    if (form == DLMCQ_FORM_EMULATE) q = clamp_nan(__builtin_rintf((v - of) / dv), lo, hi);
+    else if (form == DLMCQ_FORM_QBASE) q = ste_round(clamp_nan((v - of) / dv, lo, hi));
+    else if (form == DLMCQ_FORM_ZEROPOINT) q = clamp_nan(ste_round(v / dv) + zadd, lo, hi);
+    else q = clamp_nan(ste_round(v / dv), lo, hi);
     return (uint32_t)(code_of(q) & 0xff);
   }
+  // For a FINITE quotient d = fl(u / dv), u = v - of, all four forms reduce to  code = clamp(rint(d) + zadd, lo, hi)
+  // (rint(clamp(d)) = clamp(rint(d)) for integral bounds; the STE identity (r - d) + d returns r exactly).
   // A correctly rounded division costs ~25 VALU operations per element - more than everything else in the epilogue -
   // so d is replaced by t = fl(u * fl(1/dv)), which differs from d by less than 2^-22 |t|.  For |t| <= 512 that is
   // below 2^-13: unless t lies within 2^-12 of a rounding tie (x.5), rint(t) = rint(d); for |t| > 512 both saturate

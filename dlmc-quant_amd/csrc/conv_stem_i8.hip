@@ -36,8 +36,12 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void quantize_pad_nhwc4_kernel(const f
   const float dv = form == DLMCQ_FORM_EMULATE ? s + 1e-7f : (form == DLMCQ_FORM_QBASE ? ste_scale(s, ste_g) : s);
   const float of = (form == DLMCQ_FORM_EMULATE || form == DLMCQ_FORM_QBASE) ? z : 0.0f;
   const float zadd = form == DLMCQ_FORM_ZEROPOINT ? z : 0.0f;
-  auto code = [&](float v) -> uint32_t {   // the four forms of fq_one, reduced as in conv_epilogue.h (exact division)
-    const float q = clamp_nan(__builtin_rintf((v - of) / dv) + zadd, lo, hi);
+  auto code = [&](float v) -> uint32_t {   // fq_one, form by form (the STE identity matters for +-inf)
+    float q;
+    if (form == DLMCQ_FORM_EMULATE) q = clamp_nan(__builtin_rintf((v - of) / dv), lo, hi);
+    else if (form == DLMCQ_FORM_QBASE) q = ste_round(clamp_nan((v - of) / dv, lo, hi));
+    else if (form == DLMCQ_FORM_ZEROPOINT) q = clamp_nan(ste_round(v / dv) + zadd, lo, hi);
+    else q = clamp_nan(ste_round(v / dv), lo, hi);
     return (uint32_t)(code_of(q) & 0xff);
   };
   const uint32_t border = code(0.0f) * 0x01010101u;   // x' = 0 (zero padding of the fake-quantised image) in every channel

@@ -226,6 +226,8 @@ def test_stem_kernels_match_the_generic_path(unsigned):
         s_in = torch.tensor([float(x.abs().max()) / (127 if not unsigned else 200)], device=DEV)
         zp = torch.tensor([117.0 if unsigned else 0.0], device=DEV)
         form = N.FORM_ZEROPOINT
+        if idx == 0:     # non-finite pixels take the reference's route (R(+-inf) = NaN -> code 0)
+            x.view(-1)[torch.tensor([3, 77, 500])] = torch.tensor([float("inf"), -float("inf"), float("nan")], device=DEV)
         _, want_codes = K.fake_quant(x, s_in, zp, lo, hi, form, codes="i8", want_y=False)
         xpad = K.quantize_pad_nhwc4(x, s_in, zp, lo, hi, form, pad)
         assert xpad.shape == (n, h + 2 * pad, w + 2 * pad, 4)
@@ -355,3 +357,40 @@ def test_fused_plan_matches_the_cpu_port_end_to_end():
     print(f"fused plan vs CPU port: mean |diff| {mean_err:.4g}, logit spread {spread:.4g}, correlation {corr:.5f}")
     assert corr > 0.995 and mean_err < 0.03 * spread
     assert torch.equal(got.argmax(dim=1), want.argmax(dim=1))
+
+
+def test_epilogue_quantiser_on_exact_ties_saturation_and_nan():
+    """The reciprocal fast path of the epilogue quantiser must hand exact rounding ties (x.5), values a few ulps either
+    side of them, saturating values and NaN to the exact division: with unit scales the convolution result is an
+    exact integer, the bias moves it onto (and just off) the ties, and the consumer's scale is a power of two or an
+    awkward number.  Codes must equal the stand-alone kernel's (half-to-even, clamp, NaN -> 0) bit for bit."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    n, c, h, k = 2, 64, 6, 64
+    g = gen(900)
+    codes = torch.randint(0, 5, (n, c, h, h), generator=g).to(torch.uint8).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = torch.randint(-1, 2, (k, c, 1, 1), generator=g).float().to(DEV)
+    one = torch.ones(k, device=DEV)
+    wq, wsum = K.quantize_weight_krsc(wt, one, -127, 127)
+    s_in, zp_in = torch.tensor([1.0], device=DEV), torch.tensor([0.0], device=DEV)
+    ulp = 2.0 ** -20
+    offs = torch.tensor([0.5, -0.5, 0.5 + ulp, 0.5 - ulp, 1.5, 2.5, 0.25, 0.0], device=DEV)
+    bias = offs.repeat(k // offs.numel())
+    bias[7] = float("nan")
+    bias[15] = float("inf")
+    bias[23] = -float("inf")
+    bias[31] = 1e30
+    plain = K.conv2d_i8(codes, wq, wsum, bias, s_in, zp_in, one)
+    assert torch.isnan(plain[:, 7]).all() and bool((plain[:, 0] * 2 % 2 == 1).all())      # exact x.5 values are present
+    for q_scale, zp, lo, hi, form in [(1.0, 0.0, -127, 127, N.FORM_SYMMETRIC), (1.0, 3.0, 0, 255, N.FORM_ZEROPOINT),
+                                      (0.5, 0.0, 0, 255, N.FORM_ZEROPOINT), (0.1, 7.0, 0, 255, N.FORM_ZEROPOINT),
+                                      (1.0, 0.0, -7, 7, N.FORM_QBASE), (3.0, 0.0, 0, 15, N.FORM_EMULATE),
+                                      (1e-30, 0.0, 0, 255, N.FORM_ZEROPOINT), (1e-41, 0.0, 0, 255, N.FORM_ZEROPOINT)]:
+        qs = torch.tensor([q_scale], device=DEV)
+        qz = torch.tensor([zp], device=DEV)
+        emit = K.EmitCodes(qs, qz, lo, hi, form, 0.0)
+        for relu in (False, True):
+            want = torch.relu(plain) if relu else plain
+            _, wc = K.fake_quant(want, qs, qz, lo, hi, form, codes="i8", want_y=False)
+            _, got = K.conv2d_i8(codes, wq, wsum, bias, s_in, zp_in, one, relu=relu, emit=emit, want_out=False)
+            same(got, wc, f"scale {q_scale} zp {zp} [{lo},{hi}] form {form} relu={relu}")
