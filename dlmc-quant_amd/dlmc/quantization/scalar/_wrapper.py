@@ -194,7 +194,24 @@ def ste_scale_value(scale, g):
     return (scale.detach() - sg) + sg
 
 
-def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, wt_lo, wt_hi, g_in=0.0):
+def _cached_weight_codes(mod, wt_scale, wt_lo, wt_hi, quantise, scale_key=None):
+    """Integer weight codes of `mod`, recomputed only when the weight or its scale was written to (tensor version
+    counters: optimiser steps, load_state_dict and re-calibration all bump them).  `scale_key` identifies the scale
+    when `wt_scale` is a derived temporary (QBase's grad_scale value); without a stable identity nothing is cached."""
+    if scale_key is None:
+        if not isinstance(wt_scale, torch.nn.Parameter):
+            return quantise(mod.weight, wt_scale, wt_lo, wt_hi)
+        scale_key = (wt_scale.data_ptr(), wt_scale._version)
+    key = (mod.weight.data_ptr(), mod.weight._version, scale_key, wt_lo, wt_hi, quantise)
+    hit = getattr(mod, "_wq_cache", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    wq, wsum = quantise(mod.weight, wt_scale, wt_lo, wt_hi)
+    object.__setattr__(mod, "_wq_cache", (key, wq, wsum))
+    return wq, wsum
+
+
+def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, wt_lo, wt_hi, g_in=0.0, wt_scale_key=None):
     """Quantise the activation to integer codes (one pass, 4 B read + 1 B written per element), quantise the
     weight to KRSC int8, and contract on v_mfma_i32_32x32x32_i8 with the dequantisation fused into the epilogue.
     Same mathematical result as F.conv2d(fake_quant(x), fake_quant(w), bias); activations travel channels_last."""
@@ -202,14 +219,14 @@ def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, 
         xpad = K.quantize_pad_nhwc4(input, in_scale.detach(), in_zp, in_lo, in_hi, act_form, mod.padding[0], g=g_in)
         if g_in:
             in_scale = ste_scale_value(in_scale, g_in)
-        wq, wsum = K.quantize_weight_stem(mod.weight, wt_scale, wt_lo, wt_hi)
+        wq, wsum = _cached_weight_codes(mod, wt_scale, wt_lo, wt_hi, K.quantize_weight_stem, wt_scale_key)
         return K.conv2d_i8_stem(xpad, wq, wsum, mod.bias, in_scale, in_zp, wt_scale, mod.weight.shape[3], stride=mod.stride[0])
     if input.dim() == 4 and not input.is_contiguous(memory_format=torch.channels_last):
         input = input.contiguous(memory_format=torch.channels_last)   # one transposing copy, at the model's first int8 layer
     _, codes = K.fake_quant(input, in_scale.detach(), in_zp, in_lo, in_hi, act_form, g=g_in, codes="i8", want_y=False)
     if g_in:
         in_scale = ste_scale_value(in_scale, g_in)   # QBASE dequantises with s^, not s
-    wq, wsum = K.quantize_weight_krsc(mod.weight, wt_scale, wt_lo, wt_hi)
+    wq, wsum = _cached_weight_codes(mod, wt_scale, wt_lo, wt_hi, K.quantize_weight_krsc, wt_scale_key)
     if mod.weight.dim() == 2:
         flat = codes.reshape(-1, codes.shape[-1])
         out = K.conv2d_i8(flat, wq, wsum, mod.bias, in_scale, in_zp, wt_scale)

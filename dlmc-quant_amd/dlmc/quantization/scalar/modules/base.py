@@ -140,7 +140,8 @@ class QBase(Module):
                 g_i = 1 / math.sqrt(input.numel() * self.in_max_val)
                 g_w = 1 / math.sqrt(self.weight.numel() * self.wt_max_val)
                 return int8_forward(self, input, self.in_scale, None, self.in_min_val, self.in_max_val, N.FORM_QBASE,
-                                    ste_scale_value(self.wt_scale, g_w), self.wt_min_val, self.wt_max_val, g_in=g_i)
+                                    ste_scale_value(self.wt_scale, g_w), self.wt_min_val, self.wt_max_val, g_in=g_i,
+                                    wt_scale_key=(self.wt_scale.data_ptr(), self.wt_scale._version, g_w))
         if self.qconfig["input"]["enable"]:
             if not self._init.ready(self, "in_init_state"):
                 self._calibrate_input(input)

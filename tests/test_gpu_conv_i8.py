@@ -174,3 +174,34 @@ def test_qbase_model_int8_path_matches_fp32_path():
         c(x)
         K.PROFILE.enabled = False
     assert [t for t, *_ in K.PROFILE.records].count("conv_i8") <= 2   # only the post-ReLU (min = 0) layers qualify
+
+
+def test_module_path_weight_code_cache_follows_the_weights():
+    """The int8 module path keeps the integer weight codes between forwards and must notice every write to the weight
+    or its scale (in-place update, load_state_dict, re-calibration)."""
+    from torch import nn
+    from dlmc.utils.quantize import quantize_model
+    torch.manual_seed(2333)
+    cfg = {"weight": {"enable": True, "type": "minmax_channel", "args": {"n_bits": 8, "signed": True}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+           "exclude_layers": [], "override_options": []}
+
+    def build(int8):
+        torch.manual_seed(1)
+        net = nn.Sequential(nn.Conv2d(64, 64, 3, padding=1)).to(DEV).eval()
+        quantize_model(net, cfg, None, "FSPTQ", int8_gemm=int8)
+        return net
+    a, b = build(True), build(False)
+    x = torch.relu(torch.randn(2, 64, 8, 8, device=DEV))
+    with torch.no_grad():
+        for step in range(3):
+            ya, yb = a(x), b(x)
+            torch.testing.assert_close(ya, yb.contiguous(memory_format=torch.channels_last), rtol=1e-5, atol=1e-5)
+            assert getattr(a[0], "_wq_cache", None) is not None
+            for net in (a, b):                       # an "optimiser step": in-place, bumps the version counter
+                net[0].weight.mul_(1.5 + step)
+                net[0].wt_scale.mul_(1.5 + step)
+        sd = build(False).state_dict()
+        a.load_state_dict(sd)
+        b.load_state_dict(sd)
+        torch.testing.assert_close(a(x), b(x).contiguous(memory_format=torch.channels_last), rtol=1e-5, atol=1e-5)
