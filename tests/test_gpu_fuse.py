@@ -394,3 +394,38 @@ def test_epilogue_quantiser_on_exact_ties_saturation_and_nan():
             _, wc = K.fake_quant(want, qs, qz, lo, hi, form, codes="i8", want_y=False)
             _, got = K.conv2d_i8(codes, wq, wsum, bias, s_in, zp_in, one, relu=relu, emit=emit, want_out=False)
             same(got, wc, f"scale {q_scale} zp {zp} [{lo},{hi}] form {form} relu={relu}")
+
+
+def test_epilogue_quantiser_random_sweep():
+    """The epilogue quantiser against the stand-alone kernel over many random consumers (scale, zero point, range, form):
+    ~1.2 M values each, of which ~0.05 % land inside the tie margin and take the exact-division path."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = gen(901)
+    n, c, h, k = 4, 64, 12, 128
+    codes = torch.randint(0, 256, (n, c, h, h), generator=g).to(torch.uint8).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(k, c, 3, 3, generator=g) * 0.05).to(DEV)
+    s_w = wt.abs().amax(dim=(1, 2, 3)) / 127 + 1e-6
+    wq, wsum = K.quantize_weight_krsc(wt, s_w, -127, 127)
+    bias = torch.randn(k, generator=g).to(DEV)
+    s_in, zp_in = torch.tensor([0.0173], device=DEV), torch.tensor([2.0], device=DEV)
+    plain = K.conv2d_i8(codes, wq, wsum, bias, s_in, zp_in, s_w, padding=1)
+    vmax = float(plain.abs().max())
+    forms = [N.FORM_EMULATE, N.FORM_QBASE, N.FORM_ZEROPOINT, N.FORM_SYMMETRIC]
+    for i in range(48):
+        form = forms[i % 4]
+        bits = [8, 8, 4, 2][(i // 4) % 4]
+        signed = (i // 16) % 2 == 1 or form in (N.FORM_QBASE, N.FORM_SYMMETRIC)
+        lo, hi = (-(2 ** (bits - 1) - 1), 2 ** (bits - 1) - 1) if signed else (0, 2 ** bits - 1)
+        scale = vmax / hi * float(torch.empty(1).uniform_(0.2, 1.5, generator=g))
+        zp = 0.0 if form in (N.FORM_QBASE, N.FORM_SYMMETRIC) else float(torch.randint(lo, hi + 1, (1,), generator=g))
+        if form == N.FORM_EMULATE:
+            zp = float(torch.empty(1).uniform_(-1, 1, generator=g)) * scale       # EMULATE's offset is in value units
+        qs, qz = torch.tensor([scale], device=DEV), torch.tensor([zp], device=DEV)
+        gq = 1e-3 if form == N.FORM_QBASE else 0.0
+        emit = K.EmitCodes(qs, qz, lo, hi, form, gq)
+        relu = i % 3 == 0
+        want = torch.relu(plain) if relu else plain
+        _, wc = K.fake_quant(want, qs, qz, lo, hi, form, g=gq, codes="i8", want_y=False)
+        _, got = K.conv2d_i8(codes, wq, wsum, bias, s_in, zp_in, s_w, padding=1, relu=relu, emit=emit, want_out=False)
+        same(got, wc, f"sweep {i}: form {form} [{lo},{hi}] scale {scale:.4g} zp {zp:.4g}")
