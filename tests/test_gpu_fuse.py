@@ -398,7 +398,7 @@ def test_epilogue_quantiser_on_exact_ties_saturation_and_nan():
 
 def test_epilogue_quantiser_random_sweep():
     """The epilogue quantiser against the stand-alone kernel over many random consumers (scale, zero point, range, form):
-    ~1.2 M values each, of which ~0.05 % land inside the tie margin and take the exact-division path."""
+    74 k values each, of which ~0.05 % land inside the tie margin and take the exact-division path."""
     from dlmc import _native as N
     from dlmc.quantization.scalar import kernels as K
     g = gen(901)
