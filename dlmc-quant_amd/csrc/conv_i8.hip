@@ -1293,7 +1293,10 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int8_t* xs = reinterpret_cast<const int8_t*>(x);
   static const int bn_force = [] { const char* e = getenv("DLMCQ_CONV_BN"); return e ? atoi(e) : 0; }();   // A/B measurements only
-  const int bnn = bn_force == 64 ? 64 : ((K <= 64 || (K % 128) != 0) ? 64 : 128);
+  // 64-wide tiles: narrow outputs, and the dual kernel on short reductions (two operand pairs + the shortcut sum keep
+  // 190 VGPRs at 128 columns; measured on ResNet-50's first dual layer, 64 -> 256 channels at 56x56: 655 vs 701 us)
+  const bool dual_short = seg2 && K <= 256 && R * S * C <= 256;
+  const int bnn = (bn_force == 64 || dual_short) ? 64 : ((K <= 64 || (K % 128) != 0) ? 64 : 128);
   // 256-row tiles halve the weight-operand traffic per MAC; they pay off when the reduction is long (3x3 taps or
   // many input channels) and there are enough row tiles to fill the chip.  DLMCQ_CONV_VARIANT=2 forces 128 rows.
   const int64_t ksteps = R * S * (C / CV_BK);
