@@ -241,6 +241,11 @@ class StemLayer(_PlanLayer):
         return self._finish(out, out_codes)
 
 
+class _DryNode(nn.Module):
+    def forward(self, *args):
+        raise RuntimeError("fuse_inference(dry_run=True) builds the plan's structure only")
+
+
 class FusionReport:
     """What the pass did, for logs and tests."""
 
@@ -293,10 +298,11 @@ def _pool_params(node, modules):
     return k, s, p
 
 
-def fuse_inference(model, report=None):
+def fuse_inference(model, report=None, dry_run=False):
     """Return a `torch.fx.GraphModule` executing `model`'s calibrated quantised forward as the fused int8 plan.
     Layers that are not eligible (grouped / 3-channel convs, non-integer zero points, RootQ, ...) keep running
-    their own wrapper.  `model` must be on the GPU, in eval mode, already calibrated."""
+    their own wrapper.  `model` must be on the GPU, in eval mode, already calibrated.  `dry_run=True` only takes the
+    fusion decisions (graph + `fusion_report`, placeholder nodes): it needs no GPU and the result cannot be run."""
     if model.training:
         raise RuntimeError("fuse_inference: the plan is for inference - call model.eval() first")
     report = report if report is not None else FusionReport()
@@ -384,16 +390,18 @@ def fuse_inference(model, report=None):
         specs[name] = None
         modules[name] = None
         cls = Int8Layer if spec[4] == "gemm" else StemLayer
-        plan = cls(modules[node.target], spec, relu=relu, emit=emit, want_out=fp32_needed or emit is None, pool=pool)
         # the shortcut is itself a not-yet-planned int8 convolution read by nobody else: one dual kernel
         other = spec_of(residual) if residual is not None and residual.op == "call_module" else None
         dual = (other is not None and other[4] == "gemm" and list(residual.users) == [chain[1]] and
                 modules[node.target].weight.dim() == 4 and modules[residual.target].weight.dim() == 4)
+        if dry_run:       # decisions only (CPU-side tests): the node is a placeholder, nothing is quantised or launched
+            gm.add_module(name, _DryNode())
+        else:
+            plan = cls(modules[node.target], spec, relu=relu, emit=emit, want_out=fp32_needed or emit is None, pool=pool)
+            gm.add_module(name, DualInt8Layer(plan, Int8Layer(modules[residual.target], other)) if dual else plan)
         if dual:
-            gm.add_module(name, DualInt8Layer(plan, Int8Layer(modules[residual.target], other)))
             args = (node.args[0], residual.args[0])
         else:
-            gm.add_module(name, plan)
             args = (node.args[0],) if residual is None else (node.args[0], residual)
         with graph.inserting_after(last):
             fused = graph.call_module(name, args=args)

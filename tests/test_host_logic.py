@@ -145,3 +145,44 @@ def test_mobileone_s1_matches_the_published_size():
     rows = W.layer_table(W.mobileone_s1_deploy(), torch.zeros(1, 3, 224, 224))
     layers, act, wt, macs = W.table_totals(rows)
     assert layers == 44 and 4.7e6 < wt < 4.8e6 and 8.2e8 < macs < 8.3e8   # 4.8 M parameters, 825 MFLOPs (paper)
+
+
+def test_fusion_decisions_without_a_gpu():
+    """The dataflow pass of dlmc.utils.fuse (which ReLU / shortcut add / max-pool / consumer quantiser folds into which
+    int8 kernel) on CPU models whose wrappers are marked calibrated by hand: structure only (`dry_run`)."""
+    import workloads as W
+    from dlmc.quantization.scalar.FSPTQuant import FSPTQBase
+    from dlmc.utils.fuse import fuse_inference
+    from dlmc.utils.quantize import quantize_model
+    cfg = {"weight": {"enable": True, "type": "minmax_channel", "args": {"n_bits": 8, "signed": True}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+           "exclude_layers": [], "override_options": []}
+
+    def calibrated(net, first_layer_zp=0.0):
+        for m in net.modules():                      # BatchNorm folded by hand: the pass treats Identity as a wire
+            for name, child in list(m.named_children()):
+                if isinstance(child, torch.nn.BatchNorm2d):
+                    setattr(m, name, torch.nn.Identity())
+        quantize_model(net, cfg, None, "FSPTQ")
+        first = True
+        for m in net.modules():
+            if isinstance(m, FSPTQBase):
+                m.in_init_state.fill_(1)
+                m.wt_init_state.fill_(1)
+                m.in_offset = torch.tensor(first_layer_zp if first else 0.0)
+                first = False
+        return net.eval()
+
+    rep = fuse_inference(calibrated(W.resnet50()), dry_run=True).fusion_report
+    assert (rep.layers, rep.stem, rep.pooled, rep.dual, rep.relu, rep.residual, rep.emit, rep.fp32_outputs, rep.skipped) == (
+        54, 1, 1, 4, 49, 16, 48, 14, [])
+    rep = fuse_inference(calibrated(W.resnet50(), first_layer_zp=-2.117), dry_run=True).fusion_report
+    assert rep.stem == 0 and rep.skipped == ["conv1"] and rep.layers == 53       # non-integer zero point: fp32 first layer
+    rep = fuse_inference(calibrated(W.resnet18()), dry_run=True).fusion_report
+    assert (rep.layers, rep.stem, rep.pooled, rep.dual, rep.residual) == (21, 1, 0, 3, 8)   # the pool also feeds a shortcut
+    rep = fuse_inference(calibrated(W.repvgg_a1_deploy()), dry_run=True).fusion_report
+    assert (rep.layers, rep.stem, rep.relu, rep.emit, rep.fp32_outputs, rep.dual) == (23, 1, 22, 21, 2, 0)
+    rep = fuse_inference(calibrated(W.mobileone_s1_deploy()), dry_run=True).fusion_report
+    assert rep.stem == 1 and len(rep.skipped) == 23 and all(n.endswith(".dw") or n.endswith(".pw") for n in rep.skipped)
+    with pytest.raises(RuntimeError):
+        fuse_inference(calibrated(W.resnet18()).train(), dry_run=True)
