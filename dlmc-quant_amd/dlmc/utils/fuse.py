@@ -306,7 +306,11 @@ def fuse_inference(model, report=None, dry_run=False):
     if model.training:
         raise RuntimeError("fuse_inference: the plan is for inference - call model.eval() first")
     report = report if report is not None else FusionReport()
-    graph = _Tracer().trace(model)
+    try:
+        graph = _Tracer().trace(model)
+    except Exception as e:   # data-dependent control flow, *args signatures, ... - torch.fx says which line
+        raise RuntimeError(f"fuse_inference reads the model's dataflow with torch.fx and could not trace it ({type(e).__name__}: "
+                           f"{e}); the module-by-module path (quantize_model(..., int8_gemm=True)) needs no tracing") from e
     gm = fx.GraphModule(model, graph)
     modules = dict(gm.named_modules())
     specs = {}

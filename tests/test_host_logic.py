@@ -186,3 +186,18 @@ def test_fusion_decisions_without_a_gpu():
     assert rep.stem == 1 and len(rep.skipped) == 23 and all(n.endswith(".dw") or n.endswith(".pw") for n in rep.skipped)
     with pytest.raises(RuntimeError):
         fuse_inference(calibrated(W.resnet18()).train(), dry_run=True)
+
+
+def test_fuse_reports_untraceable_models():
+    from dlmc.utils.fuse import fuse_inference
+
+    class Dyn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv2d(64, 64, 1)
+
+        def forward(self, x):
+            return self.c(x) if x.sum() > 0 else x      # data-dependent branch: not a static dataflow
+
+    with pytest.raises(RuntimeError, match="torch.fx"):
+        fuse_inference(Dyn().eval(), dry_run=True)
