@@ -205,3 +205,49 @@ def test_module_path_weight_code_cache_follows_the_weights():
         a.load_state_dict(sd)
         b.load_state_dict(sd)
         torch.testing.assert_close(a(x), b(x).contiguous(memory_format=torch.channels_last), rtol=1e-5, atol=1e-5)
+
+
+def test_conv_i8_random_shapes_against_float64():
+    """120 random small geometries (channels, sizes, taps, stride, padding, dilation, ragged tiles) through the default
+    dispatch and the fused epilogue, against a float64 convolution of the dequantised operands."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = gen(77)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+    done = 0
+    while done < 120:
+        n, c, k = ri(1, 3), 64 * ri(1, 3), [8, 32, 64, 72, 128, 192, 256][ri(0, 6)]
+        r = [1, 3, 5][ri(0, 2)]
+        stride, dil = ri(1, 2), ri(1, 2)
+        pad = ri(0, 2)
+        h, w = ri(1, 12), ri(1, 12)
+        p, q = (h + 2 * pad - dil * (r - 1) - 1) // stride + 1, (w + 2 * pad - dil * (r - 1) - 1) // stride + 1
+        if p < 1 or q < 1:
+            continue
+        done += 1
+        unsigned = done % 2 == 0
+        lo, hi = (0, 255) if unsigned else (-127, 127)
+        codes = torch.randint(lo, hi + 1, (n, c, h, w), generator=g).to(torch.uint8 if unsigned else torch.int8)
+        zp = float(ri(0, 9)) if unsigned else 0.0
+        wt = torch.randn(k, c, r, r, generator=g) * 0.05
+        s_w = wt.abs().amax(dim=(1, 2, 3)) / 127 + 1e-6
+        bias = torch.randn(k, generator=g)
+        qw = torch.clamp(torch.round(wt / s_w.reshape(-1, 1, 1, 1)), -127, 127)
+        ref = F.conv2d((codes.double() - zp) * 0.0173, qw.double() * s_w.double().reshape(-1, 1, 1, 1), bias.double(),
+                       stride=stride, padding=pad, dilation=dil)
+        wq, wsum = K.quantize_weight_krsc(wt.to(DEV), s_w.to(DEV), -127, 127)
+        cd = codes.to(DEV).contiguous(memory_format=torch.channels_last)
+        args = (cd, wq, wsum, bias.to(DEV), torch.tensor([0.0173], device=DEV), torch.tensor([zp], device=DEV), s_w.to(DEV))
+        kw = dict(stride=stride, padding=pad, dilation=dil)
+        tag = f"shape {done}: n{n} c{c} {h}x{w} k{k} r{r} s{stride} p{pad} d{dil} {'u8' if unsigned else 's8'}"
+        got = K.conv2d_i8(*args, **kw)
+        torch.testing.assert_close(got.cpu().double(), ref, rtol=2e-6, atol=2e-5, msg=lambda m: f"{tag}: {m}")
+        res = torch.randn(got.shape, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        q_s = torch.tensor([float(ref.abs().max()) / 255 + 1e-3], device=DEV)
+        emit = K.EmitCodes(q_s, torch.tensor([0.0], device=DEV), 0, 255, N.FORM_ZEROPOINT)
+        want = torch.relu(got + res)
+        _, wc = K.fake_quant(want, q_s, emit.zero_point, 0, 255, N.FORM_ZEROPOINT, codes="i8", want_y=False)
+        out, cds = K.conv2d_i8(*args, residual=res, relu=True, emit=emit, **kw)
+        assert torch.equal(out, want) and torch.equal(cds, wc), tag + " fused epilogue"
