@@ -429,3 +429,72 @@ def test_epilogue_quantiser_random_sweep():
         _, wc = K.fake_quant(want, qs, qz, lo, hi, form, g=gq, codes="i8", want_y=False)
         _, got = K.conv2d_i8(codes, wq, wsum, bias, s_in, zp_in, s_w, padding=1, relu=relu, emit=emit, want_out=False)
         same(got, wc, f"sweep {i}: form {form} [{lo},{hi}] scale {scale:.4g} zp {zp:.4g}")
+
+
+def test_stem_and_dual_kernels_random_shapes():
+    """Random geometries for the first-layer kernel (channels 1-4, filter rows 1-7, taps 1-8, stride 1-3, padding 0-3) and
+    for the dual kernel (two operand pairs of different size / stride / taps giving one output shape)."""
+    import torch.nn.functional as F
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = gen(1234)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+    done = 0
+    while done < 40:
+        n, c, r, s, stride, pad = ri(1, 3), ri(1, 4), ri(1, 7), ri(1, 8), ri(1, 3), ri(0, 3)
+        h, w, k = ri(1, 20), ri(1, 20), 4 * ri(1, 24)
+        if h + 2 * pad < r or w + 2 * pad < s:
+            continue
+        done += 1
+        x = torch.randn(n, c, h, w, generator=g).to(DEV)
+        if done % 2:
+            x = x.contiguous(memory_format=torch.channels_last)
+        unsigned = done % 3 != 0
+        lo, hi = (0, 255) if unsigned else (-127, 127)
+        s_in = torch.tensor([float(x.abs().max()) / 120 + 1e-3], device=DEV)
+        zp = torch.tensor([float(ri(100, 140)) if unsigned else 0.0], device=DEV)
+        _, codes = K.fake_quant(x, s_in, zp, lo, hi, N.FORM_ZEROPOINT, codes="i8", want_y=False)
+        wt = (torch.randn(k, c, r, s, generator=g) * 0.1).to(DEV)
+        s_w = wt.abs().amax(dim=(1, 2, 3)) / 127 + 1e-6
+        bias = torch.randn(k, generator=g).to(DEV)
+        qw = torch.clamp(torch.round(wt.cpu() / s_w.cpu().reshape(-1, 1, 1, 1)), -127, 127)
+        ref = F.conv2d((codes.cpu().double() - float(zp)) * float(s_in), qw.double() * s_w.cpu().double().reshape(-1, 1, 1, 1),
+                       bias.cpu().double(), stride=stride, padding=pad)
+        xpad = K.quantize_pad_nhwc4(x, s_in, zp, lo, hi, N.FORM_ZEROPOINT, pad)
+        wq, wsum = K.quantize_weight_stem(wt, s_w, -127, 127)
+        got = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=stride)
+        torch.testing.assert_close(got.cpu().double(), ref, rtol=2e-6, atol=2e-5,
+                                   msg=lambda m: f"stem {done}: n{n} c{c} {h}x{w} k{k} {r}x{s} s{stride} p{pad}: {m}")
+    done = 0
+    while done < 24:
+        n, k = ri(1, 3), [32, 64, 128, 192, 256][ri(0, 4)]
+        p_out = ri(1, 9)
+
+        def operand(unsigned):
+            c, r, stride = 64 * ri(1, 2), [1, 3][ri(0, 1)], ri(1, 2)
+            pad = r // 2
+            h = (p_out - 1) * stride + 1 + ri(0, stride - 1)      # any input size giving p_out rows
+            lo, hi = (0, 256) if unsigned else (-127, 128)
+            codes = torch.randint(lo, hi, (n, c, h, h), generator=g).to(torch.uint8 if unsigned else torch.int8).to(DEV)
+            wt = (torch.randn(k, c, r, r, generator=g) * 0.05).to(DEV)
+            s_w = wt.abs().amax(dim=(1, 2, 3)) / 127 + 1e-6
+            wq, wsum = K.quantize_weight_krsc(wt, s_w, -127, 127)
+            return dict(codes=codes.contiguous(memory_format=torch.channels_last), wq=wq, wsum=wsum,
+                        bias=torch.randn(k, generator=g).to(DEV) if ri(0, 1) else None,
+                        in_scale=torch.tensor([0.01 + 0.001 * ri(0, 9)], device=DEV),
+                        in_zp=torch.tensor([float(ri(0, 9)) if unsigned else 0.0], device=DEV), w_scale=s_w, stride=stride, padding=pad)
+        a, b = operand(True), operand(done % 2 == 0)
+        done += 1
+
+        def single(t):
+            return K.conv2d_i8(t["codes"], t["wq"], t["wsum"], t["bias"], t["in_scale"], t["in_zp"], t["w_scale"],
+                               stride=t["stride"], padding=t["padding"])
+        want = torch.relu(single(a) + single(b))
+        q_s = torch.tensor([float(want.max()) / 255 + 1e-3], device=DEV)
+        emit = K.EmitCodes(q_s, torch.tensor([0.0], device=DEV), 0, 255, N.FORM_ZEROPOINT)
+        _, wc = K.fake_quant(want, q_s, emit.zero_point, 0, 255, N.FORM_ZEROPOINT, codes="i8", want_y=False)
+        out, codes = K.conv2d_i8_dual(a, b, relu=True, emit=emit)
+        same(out, want, f"dual {done} out")
+        same(codes, wc, f"dual {done} codes")
