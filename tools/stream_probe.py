@@ -26,7 +26,8 @@ with torch.no_grad():
     model(x)
     plan = fuse_inference(model)
     ref = plan(x)
-    for S in (1, 2, 3, 4):
+    import itertools
+    for S, skew_us in itertools.chain(((s, 0) for s in (1, 2, 3, 4)), ((2, k) for k in (50, 100, 200, 400, 800))):
         streams = [torch.cuda.Stream() for _ in range(S)]
         parts = list(x.chunk(S, dim=0))
 
@@ -37,6 +38,8 @@ with torch.no_grad():
                 s.wait_stream(cur)
             for i, s in enumerate(streams):
                 with torch.cuda.stream(s):
+                    if i and skew_us:
+                        torch.cuda._sleep(int(skew_us * 1e-6 * 2.1e9) * i)     # start this share later (shader clocks)
                     outs[i] = plan(parts[i])
             for s in streams:
                 cur.wait_stream(s)
@@ -49,4 +52,4 @@ with torch.no_grad():
             out = run()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 10 * 1e3
-        print(f"{S} stream(s): {ms:.3f} ms  {batch / ms * 1e3:.0f} images/s  identical={torch.equal(out, ref)}", flush=True)
+        print(f"{S} stream(s) skew {skew_us} us: {ms:.3f} ms  {batch / ms * 1e3:.0f} images/s  identical={torch.equal(out, ref)}", flush=True)
