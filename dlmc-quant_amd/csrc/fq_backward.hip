@@ -11,19 +11,35 @@
 namespace dlmcq {
 
 struct BwdConst {
-  float sh;  // s^
-  float of;
-  __device__ __forceinline__ BwdConst(float s, float o, float g) : sh(ste_scale(s, g)), of(o) {}
+  float sh;  // the divisor: s^ (QBASE) or s
+  float of;  // QBASE: the offset subtracted before the division;  ZEROPOINT: the zero point added after the rounding
+  int form;
+  __device__ __forceinline__ BwdConst(float s, float o, float g, int f)
+      : sh(f == DLMCQ_FORM_QBASE ? ste_scale(s, g) : s), of(f == DLMCQ_FORM_SYMMETRIC ? 0.0f : o), form(f) {}
 };
 
+// QBASE:      v = (x - o)/s^,  inside = [lo <= v <= hi],              q = R(clamp(v)),  gs += gy*(q - inside*v)
+// ZEROPOINT:  u = x/s, a = R(u) + zp, inside = [lo <= a <= hi], t = clamp(a) - zp,       gs += gy*(t - inside*u)
+// SYMMETRIC:  ZEROPOINT with zp = 0     (FSPTQuant/base.py:108-109, 149-152 as autograd runs them: the rounding is a
+//             straight-through identity, torch.clamp passes the gradient on the closed interval, x/s gives gx = g/s)
+// gx = inside ? (gy*s)/s : +0 in all three - the two roundings autograd performs.
 __device__ __forceinline__ void bwd_one(float x, float gy, const BwdConst& c, float lo, float hi, float& gx,
                                         float& contrib) {
-  const float v = (x - c.of) / c.sh;
-  const float q = ste_round(clamp_nan(v, lo, hi));
-  const bool inside = (v >= lo) && (v <= hi);
+  float v, q;
+  bool inside;
+  if (c.form == DLMCQ_FORM_QBASE) {
+    v = (x - c.of) / c.sh;
+    q = ste_round(clamp_nan(v, lo, hi));
+    inside = (v >= lo) && (v <= hi);
+  } else {
+    v = x / c.sh;
+    const float a = ste_round(v) + c.of;
+    inside = (a >= lo) && (a <= hi);
+    q = clamp_nan(a, lo, hi) - c.of;
+  }
   const float gv = inside ? gy * c.sh : 0.0f;
   gx = gv / c.sh;                               // bit-exact with autograd's mul-then-div
-  // autograd accumulates gy*q and -gv*(v/s^) separately; gv*(v/s^) == gy*v up to rounding and the scale
+  // autograd accumulates gy*q and -gv*(v/s) separately; gv*(v/s) == gy*v up to rounding and the scale
   // gradient is an order-dependent sum anyway, so the third division is not spent: gy*(q - [inside]*v)
   contrib = gy * (q - (inside ? v : 0.0f));
 }
@@ -47,9 +63,9 @@ template <int U, bool VEC>
 __global__ __launch_bounds__(DLMCQ_BLOCK) void fq_bwd_tensor_kernel(const float* x, const float* gy, float* gx,
                                                                    const float* __restrict__ scale,
                                                                    const float* __restrict__ offset, int64_t n,
-                                                                   float lo, float hi, float g,
+                                                                   float lo, float hi, float g, int form,
                                                                    float* __restrict__ partials) {
-  const BwdConst c(scale[0], offset ? offset[0] : 0.0f, g);
+  const BwdConst c(scale[0], offset ? offset[0] : 0.0f, g, form);
   float acc = 0.0f;
   if (VEC) {
     const int64_t n4 = n >> 2;
@@ -107,10 +123,10 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void fq_bwd_rows_kernel(const float* x
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ offset, int64_t outer,
                                                                  int64_t channels, int64_t inner, int64_t npseg,
-                                                                 float lo, float hi, float g,
+                                                                 float lo, float hi, float g, int form,
                                                                  float* __restrict__ partials) {
   const int64_t c = blockIdx.x, sg = blockIdx.y;
-  const BwdConst k(scale[c], offset ? offset[c] : 0.0f, g);
+  const BwdConst k(scale[c], offset ? offset[c] : 0.0f, g, form);
   const int64_t n_lo = sg * npseg;
   const int64_t n_hi = (n_lo + npseg < outer) ? n_lo + npseg : outer;
   float acc = 0.0f;
@@ -208,11 +224,13 @@ extern "C" size_t dlmcq_fq_bwd_scratch_bytes(int64_t outer, int64_t channels, in
   return (size_t)(p.nseg * channels) * sizeof(float);
 }
 
-extern "C" int dlmcq_fake_quant_bwd_f32(const float* x, const float* gy, float* gx, float* gscale, const float* scale,
-                                        const float* offset, int64_t outer, int64_t channels, int64_t inner,
-                                        int32_t lo, int32_t hi, float ste_g, void* scratch, size_t scratch_bytes,
-                                        dlmcq_stream_t stream) {
+extern "C" int dlmcq_fake_quant_bwd_form_f32(const float* x, const float* gy, float* gx, float* gscale, const float* scale,
+                                             const float* offset, int64_t outer, int64_t channels, int64_t inner,
+                                             int32_t lo, int32_t hi, int32_t form, float ste_g, void* scratch,
+                                             size_t scratch_bytes, dlmcq_stream_t stream) {
   if (outer < 0 || channels < 1 || inner < 0 || lo > hi) return DLMCQ_EINVAL;
+  if (form != DLMCQ_FORM_QBASE && form != DLMCQ_FORM_ZEROPOINT && form != DLMCQ_FORM_SYMMETRIC) return DLMCQ_EINVAL;
+  if (form != DLMCQ_FORM_QBASE) ste_g = 1.0f;     // g scales the QBASE scale gradient only
   const int64_t n = outer * channels * inner;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n == 0) {
@@ -229,18 +247,18 @@ extern "C" int dlmcq_fake_quant_bwd_f32(const float* x, const float* gy, float* 
   if (channels == 1) {
     if (al)
       hipLaunchKernelGGL((fq_bwd_tensor_kernel<BWD_U, true>), dim3(p.grid_x), dim3(DLMCQ_BLOCK), 0, st, x, gy, gx, scale,
-                         offset, n, flo, fhi, ste_g, part);
+                         offset, n, flo, fhi, ste_g, form, part);
     else
       hipLaunchKernelGGL((fq_bwd_tensor_kernel<BWD_U, false>), dim3(p.grid_x), dim3(DLMCQ_BLOCK), 0, st, x, gy, gx,
-                         scale, offset, n, flo, fhi, ste_g, part);
+                         scale, offset, n, flo, fhi, ste_g, form, part);
   } else {
     const dim3 grid(p.grid_x, (uint32_t)p.nseg);
     if (al && inner % 4 == 0)
       hipLaunchKernelGGL((fq_bwd_rows_kernel<true>), grid, dim3(DLMCQ_BLOCK), 0, st, x, gy, gx, scale, offset, outer,
-                         channels, inner, p.npseg, flo, fhi, ste_g, part);
+                         channels, inner, p.npseg, flo, fhi, ste_g, form, part);
     else
       hipLaunchKernelGGL((fq_bwd_rows_kernel<false>), grid, dim3(DLMCQ_BLOCK), 0, st, x, gy, gx, scale, offset, outer,
-                         channels, inner, p.npseg, flo, fhi, ste_g, part);
+                         channels, inner, p.npseg, flo, fhi, ste_g, form, part);
   }
   int rc = launch_status();
   if (rc != DLMCQ_OK || !gscale) return rc;
@@ -251,4 +269,12 @@ extern "C" int dlmcq_fake_quant_bwd_f32(const float* x, const float* gy, float* 
   const int g = (int)((channels + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK);
   hipLaunchKernelGGL(fq_bwd_finalize_kernel, dim3(g), dim3(DLMCQ_BLOCK), 0, st, part, p.nseg, channels, ste_g, gscale);
   return launch_status();
+}
+
+extern "C" int dlmcq_fake_quant_bwd_f32(const float* x, const float* gy, float* gx, float* gscale, const float* scale,
+                                        const float* offset, int64_t outer, int64_t channels, int64_t inner,
+                                        int32_t lo, int32_t hi, float ste_g, void* scratch, size_t scratch_bytes,
+                                        dlmcq_stream_t stream) {
+  return dlmcq_fake_quant_bwd_form_f32(x, gy, gx, gscale, scale, offset, outer, channels, inner, lo, hi, DLMCQ_FORM_QBASE, ste_g,
+                                       scratch, scratch_bytes, stream);
 }

@@ -64,8 +64,8 @@ def _composite(form, x, scale, offset, lo, hi, g):
 
 
 class FakeQuantFn(torch.autograd.Function):
-    """y = fake_quant(x; scale, offset) for any form.  Forward: one HIP launch.  Backward: HIP for
-    FORM_QBASE, composite recompute otherwise."""
+    """y = fake_quant(x; scale, offset) for any form.  Forward: one HIP launch.  Backward: one HIP pass for
+    FORM_QBASE / FORM_ZEROPOINT / FORM_SYMMETRIC (the QBase and FSPTQ families), composite recompute otherwise."""
 
     @staticmethod
     def forward(ctx, x, scale, offset, lo, hi, form, g):
@@ -79,8 +79,8 @@ class FakeQuantFn(torch.autograd.Function):
         x, scale, offset = ctx.saved_tensors
         need_x, need_s = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gx = gs = None
-        if form == N.FORM_QBASE:
-            gx, gsv = K.fake_quant_backward(x, gy, scale.detach(), offset, lo, hi, g, want_gx=need_x, want_gscale=need_s)
+        if form in (N.FORM_QBASE, N.FORM_ZEROPOINT, N.FORM_SYMMETRIC) and x.is_contiguous() and gy.is_contiguous():
+            gx, gsv = K.fake_quant_backward(x, gy, scale.detach(), offset, lo, hi, g, want_gx=need_x, want_gscale=need_s, form=form)
             if need_s:
                 gs = gsv.reshape(scale.shape)
         else:

@@ -520,8 +520,9 @@ def unpack_int4(packed, n, signed):
     return codes if signed else codes.view(torch.uint8)
 
 
-def fake_quant_backward(x, gy, scale, offset, lo, hi, g, ch_axis=None, want_gx=True, want_gscale=True):
-    """Backward of FORM_QBASE: (gx, gscale[C]) - gx bit-exact with autograd, gscale a deterministic tree sum."""
+def fake_quant_backward(x, gy, scale, offset, lo, hi, g, ch_axis=None, want_gx=True, want_gscale=True, form=None):
+    """Backward of FORM_QBASE (default), FORM_ZEROPOINT or FORM_SYMMETRIC: (gx, gscale[C]) - gx bit-exact with autograd,
+    gscale a deterministic tree sum."""
     N.require_gpu(x, gy)
     x, gy = x.contiguous(), gy.contiguous()
     scale, offset = _f32c(scale, x), _f32c(offset, x)
@@ -532,9 +533,9 @@ def fake_quant_backward(x, gy, scale, offset, lo, hi, g, ch_axis=None, want_gx=T
     gs = torch.empty(ch, dtype=torch.float32, device=x.device) if want_gscale else None
     nb = N.lib.dlmcq_fq_bwd_scratch_bytes(outer, ch, inner)
     sc = _scratch(nb, x.device)
-    N.check(N.lib.dlmcq_fake_quant_bwd_f32(N.ptr(x), N.ptr(gy), N.ptr(gx), N.ptr(gs), N.ptr(scale), N.ptr(offset), outer,
-                                           ch, inner, int(lo), int(hi), float(g), N.ptr(sc), sc.numel() * 4,
-                                           N.stream_ptr()))
+    N.check(N.lib.dlmcq_fake_quant_bwd_form_f32(N.ptr(x), N.ptr(gy), N.ptr(gx), N.ptr(gs), N.ptr(scale), N.ptr(offset), outer,
+                                                ch, inner, int(lo), int(hi), int(N.FORM_QBASE if form is None else form), float(g),
+                                                N.ptr(sc), sc.numel() * 4, N.stream_ptr()))
     return gx, gs
 
 

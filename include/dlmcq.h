@@ -170,6 +170,17 @@ int dlmcq_fake_quant_bwd_f32(const float* x, const float* gy, float* gx, float* 
                              const float* scale, const float* offset, int64_t outer,
                              int64_t channels, int64_t inner, int32_t lo, int32_t hi, float ste_g,
                              void* scratch, size_t scratch_bytes, dlmcq_stream_t stream);
+/*
+ * The same for the FSPTQ forms, as autograd executes FSPTQuant/base.py:108-109 (DLMCQ_FORM_ZEROPOINT, offset = zero
+ * point: u = x/s, a = R(u) + zp, inside = [lo <= a <= hi], gscale = sum gy*((clamp(a) - zp) - inside*u)) and :149-152
+ * (DLMCQ_FORM_SYMMETRIC, per-channel weight scale, no offset); DLMCQ_FORM_QBASE is the call above.  ste_g is used by
+ * QBASE only.
+ */
+int dlmcq_fake_quant_bwd_form_f32(const float* x, const float* gy, float* gx, float* gscale,
+                                  const float* scale, const float* offset, int64_t outer,
+                                  int64_t channels, int64_t inner, int32_t lo, int32_t hi, int32_t form,
+                                  float ste_g, void* scratch, size_t scratch_bytes,
+                                  dlmcq_stream_t stream);
 
 /*
  * RootQ weight forward (RootQ/base.py:146-155 + RootQ/function.py:15-32,58-67), per tensor.

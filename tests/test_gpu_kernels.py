@@ -538,3 +538,40 @@ def test_fuzz_shapes_forms_alignments(K):
         ws, wo = (O.minmax_tensor(x, bits, signed) if ch_axis is None else O.minmax_channel(x, bits, signed, ch_axis=ch_axis))
         values_equal(so, ws, tag + " scale")
         values_equal(oo, wo, tag + " offset")
+
+
+def test_fsptq_forms_backward_matches_autograd_of_the_reference_chain():
+    """One-pass HIP backward of the FSPTQ forms (ZEROPOINT activations per tensor, SYMMETRIC weights per channel) against
+    autograd through the reference's op chain on the same device: gx bit for bit, the scale gradient to sum tolerance."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import _wrapper as Wr
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator().manual_seed(2333)
+    cases = [("zeropoint", N.FORM_ZEROPOINT, (4, 16, 9, 9), None, 0, 255, 3.0),
+             ("zeropoint s8", N.FORM_ZEROPOINT, (3, 8, 5, 7), None, -127, 127, 0.0),
+             ("symmetric ch0", N.FORM_SYMMETRIC, (32, 16, 3, 3), 0, -127, 127, 0.0),
+             ("symmetric 4 bit", N.FORM_SYMMETRIC, (24, 40), 0, -7, 7, 0.0)]
+    for name, form, shape, ch_axis, lo, hi, zp in cases:
+        x = (torch.randn(shape, generator=g) * 2).to(DEV)
+        gy = torch.randn(shape, generator=g).to(DEV)
+        if ch_axis is None:
+            scale = torch.tensor([float(x.abs().max()) / 100], device=DEV)
+            bshape = (1,)
+        else:
+            scale = (x.abs().amax(dim=tuple(range(1, x.dim()))) / (hi * 0.8)).reshape(-1)
+            bshape = (shape[0],) + (1,) * (len(shape) - 1)
+        offset = torch.tensor([zp], device=DEV) if ch_axis is None else None
+        xr = x.clone().requires_grad_(True)
+        sr = scale.clone().reshape(bshape).requires_grad_(True)
+        off = offset if offset is not None else torch.zeros((), device=DEV)
+        y = Wr._composite(form, xr, sr, off, lo, hi, 0.0)
+        y.backward(gy)
+        gx, gs = K.fake_quant_backward(x, gy, scale, offset, lo, hi, 0.0, ch_axis=ch_axis, form=form)
+        assert_bits_equal(gx, xr.grad, name + " gx")
+        torch.testing.assert_close(gs.reshape(-1), sr.grad.reshape(-1), rtol=2e-4, atol=1e-4, msg=lambda m: f"{name} gscale: {m}")
+        # and through the autograd Function the wrappers use
+        xr2 = x.clone().requires_grad_(True)
+        sr2 = scale.clone().reshape(bshape).requires_grad_(True)
+        Wr.fake_quant(xr2, sr2, offset, lo, hi, form).backward(gy)
+        assert_bits_equal(xr2.grad, xr.grad, name + " Function gx")
+        torch.testing.assert_close(sr2.grad, sr.grad, rtol=2e-4, atol=1e-4)
