@@ -12,10 +12,13 @@ namespace dlmcq {
 
 struct BwdConst {
   float sh;  // the divisor: s^ (QBASE) or s
-  float of;  // QBASE: the offset subtracted before the division;  ZEROPOINT: the zero point added after the rounding
+  float of;  // QBASE: the offset subtracted before the division;  ZEROPOINT: the zero point added after the rounding;
+             // ROOTQ_ACT: the upper clip s*(hi - lo)
+  float span;  // ROOTQ_ACT: hi - lo
   int form;
-  __device__ __forceinline__ BwdConst(float s, float o, float g, int f)
-      : sh(f == DLMCQ_FORM_QBASE ? ste_scale(s, g) : s), of(f == DLMCQ_FORM_SYMMETRIC ? 0.0f : o), form(f) {}
+  __device__ __forceinline__ BwdConst(float s, float o, float g, int f, float lo, float hi)
+      : sh(f == DLMCQ_FORM_QBASE ? ste_scale(s, g) : s),
+        of(f == DLMCQ_FORM_SYMMETRIC ? 0.0f : (f == DLMCQ_FORM_ROOTQ_ACT ? s * (hi - lo) : o)), span(hi - lo), form(f) {}
 };
 
 // QBASE:      v = (x - o)/s^,  inside = [lo <= v <= hi],              q = R(clamp(v)),  gs += gy*(q - inside*v)
@@ -27,6 +30,20 @@ __device__ __forceinline__ void bwd_one(float x, float gy, const BwdConst& c, fl
                                         float& contrib) {
   float v, q;
   bool inside;
+  if (c.form == DLMCQ_FORM_ROOTQ_ACT) {
+    // RootQ/base.py:106-111 + function.py:15-20 as autograd runs them: t1 = x + relu(0 - x), t = t1 - relu(t1 - up),
+    // u = t/s, y = R(u)*s.  A clipped element passes no gradient to x (gt - gt = +0); the scale collects gy*R(u) from the
+    // product, -gy*u from the division and, through up = s*(hi - lo), gy*(hi - lo) from every element clipped above.
+    const float t1 = x + relu_nan(0.0f - x);
+    const bool below = (0.0f - x) > 0.0f, above = (t1 - c.of) > 0.0f;
+    const float t = t1 - relu_nan(t1 - c.of);
+    v = t / c.sh;
+    q = ste_round(v);
+    const float gv = (below || above) ? 0.0f : gy * c.sh;
+    gx = gv / c.sh;
+    contrib = gy * (q - v) + (above ? gy * c.span : 0.0f);
+    return;
+  }
   if (c.form == DLMCQ_FORM_QBASE) {
     v = (x - c.of) / c.sh;
     q = ste_round(clamp_nan(v, lo, hi));
@@ -65,7 +82,7 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void fq_bwd_tensor_kernel(const float*
                                                                    const float* __restrict__ offset, int64_t n,
                                                                    float lo, float hi, float g, int form,
                                                                    float* __restrict__ partials) {
-  const BwdConst c(scale[0], offset ? offset[0] : 0.0f, g, form);
+  const BwdConst c(scale[0], offset ? offset[0] : 0.0f, g, form, lo, hi);
   float acc = 0.0f;
   if (VEC) {
     const int64_t n4 = n >> 2;
@@ -126,7 +143,7 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void fq_bwd_rows_kernel(const float* x
                                                                  float lo, float hi, float g, int form,
                                                                  float* __restrict__ partials) {
   const int64_t c = blockIdx.x, sg = blockIdx.y;
-  const BwdConst k(scale[c], offset ? offset[c] : 0.0f, g, form);
+  const BwdConst k(scale[c], offset ? offset[c] : 0.0f, g, form, lo, hi);
   const int64_t n_lo = sg * npseg;
   const int64_t n_hi = (n_lo + npseg < outer) ? n_lo + npseg : outer;
   float acc = 0.0f;
@@ -229,7 +246,8 @@ extern "C" int dlmcq_fake_quant_bwd_form_f32(const float* x, const float* gy, fl
                                              int32_t lo, int32_t hi, int32_t form, float ste_g, void* scratch,
                                              size_t scratch_bytes, dlmcq_stream_t stream) {
   if (outer < 0 || channels < 1 || inner < 0 || lo > hi) return DLMCQ_EINVAL;
-  if (form != DLMCQ_FORM_QBASE && form != DLMCQ_FORM_ZEROPOINT && form != DLMCQ_FORM_SYMMETRIC) return DLMCQ_EINVAL;
+  if (form != DLMCQ_FORM_QBASE && form != DLMCQ_FORM_ZEROPOINT && form != DLMCQ_FORM_SYMMETRIC && form != DLMCQ_FORM_ROOTQ_ACT)
+    return DLMCQ_EINVAL;
   if (form != DLMCQ_FORM_QBASE) ste_g = 1.0f;     // g scales the QBASE scale gradient only
   const int64_t n = outer * channels * inner;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -521,8 +521,8 @@ def unpack_int4(packed, n, signed):
 
 
 def fake_quant_backward(x, gy, scale, offset, lo, hi, g, ch_axis=None, want_gx=True, want_gscale=True, form=None):
-    """Backward of FORM_QBASE (default), FORM_ZEROPOINT or FORM_SYMMETRIC: (gx, gscale[C]) - gx bit-exact with autograd,
-    gscale a deterministic tree sum."""
+    """Backward of FORM_QBASE (default), FORM_ZEROPOINT, FORM_SYMMETRIC or FORM_ROOTQ_ACT: (gx, gscale[C]) - gx bit-exact
+    with autograd, gscale a deterministic tree sum."""
     N.require_gpu(x, gy)
     x, gy = x.contiguous(), gy.contiguous()
     scale, offset = _f32c(scale, x), _f32c(offset, x)

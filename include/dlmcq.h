@@ -173,8 +173,9 @@ int dlmcq_fake_quant_bwd_f32(const float* x, const float* gy, float* gx, float* 
 /*
  * The same for the FSPTQ forms, as autograd executes FSPTQuant/base.py:108-109 (DLMCQ_FORM_ZEROPOINT, offset = zero
  * point: u = x/s, a = R(u) + zp, inside = [lo <= a <= hi], gscale = sum gy*((clamp(a) - zp) - inside*u)) and :149-152
- * (DLMCQ_FORM_SYMMETRIC, per-channel weight scale, no offset); DLMCQ_FORM_QBASE is the call above.  ste_g is used by
- * QBASE only.
+ * (DLMCQ_FORM_SYMMETRIC, per-channel weight scale, no offset), and for the RootQ activation form
+ * (DLMCQ_FORM_ROOTQ_ACT, RootQ/base.py:106-111: clipped elements pass nothing to x; the scale also collects
+ * gy*(hi - lo) from every element clipped above); DLMCQ_FORM_QBASE is the call above.  ste_g is used by QBASE only.
  */
 int dlmcq_fake_quant_bwd_form_f32(const float* x, const float* gy, float* gx, float* gscale,
                                   const float* scale, const float* offset, int64_t outer,

@@ -575,3 +575,25 @@ def test_fsptq_forms_backward_matches_autograd_of_the_reference_chain():
         Wr.fake_quant(xr2, sr2, offset, lo, hi, form).backward(gy)
         assert_bits_equal(xr2.grad, xr.grad, name + " Function gx")
         torch.testing.assert_close(sr2.grad, sr.grad, rtol=2e-4, atol=1e-4)
+
+
+def test_rootq_activation_backward_matches_autograd_of_the_reference_chain():
+    """Fused backward of the RootQ activation form against autograd through RootQ/base.py:106-111's ops."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    from dlmc.quantization.scalar.RootQ import base as RB
+    g = torch.Generator().manual_seed(77)
+    for shape, lo, hi, smul in (((4, 16, 9, 9), 0, 15, 0.15), ((3, 7, 5), 0, 3, 0.5), ((2, 8, 4, 4), 0, 255, 0.01)):
+        x = (torch.randn(shape, generator=g) * 1.5).to(DEV)
+        x.view(-1)[:4] = torch.tensor([0.0, -0.0, 1e-9, -1e-9], device=DEV)
+        gy = torch.randn(shape, generator=g).to(DEV)
+        s = torch.tensor(smul, device=DEV)
+        xr, sr = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        RB._act_composite(xr, sr, lo, hi).backward(gy)
+        gx, gs = K.fake_quant_backward(x, gy, s.reshape(1), None, lo, hi, 0.0, form=N.FORM_ROOTQ_ACT)
+        assert_bits_equal(gx, xr.grad, f"rootq act gx {shape}")
+        torch.testing.assert_close(gs.reshape(()), sr.grad, rtol=2e-4, atol=1e-3)
+        xr2, sr2 = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        RB._RootQActFn.apply(xr2, sr2, lo, hi).backward(gy)
+        assert_bits_equal(xr2.grad, xr.grad, "Function gx")
+        torch.testing.assert_close(sr2.grad, sr.grad, rtol=2e-4, atol=1e-3)
