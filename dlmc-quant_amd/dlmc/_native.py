@@ -35,6 +35,8 @@ SIGNATURES = {
     "dlmcq_unpack_int4": (ctypes.c_int, [_p, _p, _i64, _i32, _p]),
     "dlmcq_fq_bwd_scratch_bytes": (_sz, [_i64, _i64, _i64]),
     "dlmcq_fake_quant_bwd_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _f32, _p, _sz, _p]),
+    "dlmcq_rootq_bwd_scratch_bytes": (ctypes.c_size_t, [_i64]),
+    "dlmcq_rootq_weight_bwd_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _sz, _p]),
     "dlmcq_fake_quant_bwd_form_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _p, _sz, _p]),
     "dlmcq_rootq_weight_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
     "dlmcq_l2norm_scratch_bytes": (_sz, [_i64, _i64, _i64]),

@@ -71,6 +71,11 @@ class _RootQWeightFn(torch.autograd.Function):
     def backward(ctx, gy):
         lo, hi = ctx.rng
         need = ctx.needs_input_grad[:4]
+        w, upper, lower, alpha = ctx.saved_tensors
+        if gy.is_contiguous() and w.is_contiguous() and all(t.numel() == 1 for t in (upper, lower, alpha)):
+            gw, gu, gl, ga = K.rootq_weight_backward(w, gy, upper, lower, alpha, lo, hi, want_gw=need[0])   # 2 launches, not ~35
+            outs = (gw, gu.reshape(upper.shape), gl.reshape(lower.shape), ga.reshape(alpha.shape))
+            return (*[o if n else None for o, n in zip(outs, need)], None, None)
         with torch.enable_grad():
             leaves = [t.detach().requires_grad_(n) for t, n in zip(ctx.saved_tensors, need)]
             y = _weight_composite(*leaves, lo, hi)

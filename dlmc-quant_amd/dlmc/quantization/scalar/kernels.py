@@ -547,3 +547,18 @@ def rootq_weight(w, upper, lower, lo, hi):
     y = torch.empty_like(w)
     N.check(N.lib.dlmcq_rootq_weight_f32(N.ptr(w), N.ptr(y), N.ptr(bounds), w.numel(), int(lo), int(hi), N.stream_ptr()))
     return y
+
+
+def rootq_weight_backward(w, gy, upper, lower, alpha, lo, hi, want_gw=True):
+    """Backward of rootq_weight: (gw or None, g_upper, g_lower, g_alpha) - 0-dim tensors for the three scalars."""
+    N.require_gpu(w, gy)
+    w, gy = w.contiguous(), gy.contiguous()
+    bounds = torch.stack([upper.detach().reshape(()).float(), lower.detach().reshape(()).float()]).to(w.device)
+    al = alpha.detach().reshape(1).float().to(w.device)
+    gw = torch.empty_like(w) if want_gw else None
+    out = torch.empty(3, dtype=torch.float32, device=w.device)
+    sc = _scratch(N.lib.dlmcq_rootq_bwd_scratch_bytes(w.numel()), w.device)
+    N.check(N.lib.dlmcq_rootq_weight_bwd_f32(N.ptr(w), N.ptr(gy), N.ptr(gw), N.ptr(out), N.ptr(bounds), N.ptr(al), w.numel(), int(lo),
+                                             int(hi), N.ptr(sc), sc.numel() * 4, N.stream_ptr()))
+    return gw, out[0], out[1], out[2]
+

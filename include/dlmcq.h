@@ -191,6 +191,17 @@ int dlmcq_fake_quant_bwd_form_f32(const float* x, const float* gy, float* gx, fl
 int dlmcq_rootq_weight_f32(const float* w, float* y, const float* bounds, int64_t n, int32_t lo,
                            int32_t hi, dlmcq_stream_t stream);
 
+/*
+ * Backward of that transform as autograd runs the reference's op chain (RootQ/base.py:146-155 + function.py:15-32,58-67;
+ * the sign and the floor are straight-through): gw[n] (nullable) and g_bounds_alpha = {g_upper, g_lower, g_alpha}.
+ * alpha: device scalar.  scratch: dlmcq_rootq_bwd_scratch_bytes(n).  Two launches instead of the ~35 elementwise ones
+ * the op chain costs per layer per step.
+ */
+size_t dlmcq_rootq_bwd_scratch_bytes(int64_t n);
+int dlmcq_rootq_weight_bwd_f32(const float* w, const float* gy, float* gw, float* g_bounds_alpha,
+                               const float* bounds, const float* alpha, int64_t n, int32_t lo, int32_t hi,
+                               void* scratch, size_t scratch_bytes, dlmcq_stream_t stream);
+
 /* ---- weight transforms that precede the path in the few-shot PTQ flow (FSPTQuant.py:65-67) ---- */
 
 /*

@@ -597,3 +597,31 @@ def test_rootq_activation_backward_matches_autograd_of_the_reference_chain():
         RB._RootQActFn.apply(xr2, sr2, lo, hi).backward(gy)
         assert_bits_equal(xr2.grad, xr.grad, "Function gx")
         torch.testing.assert_close(sr2.grad, sr.grad, rtol=2e-4, atol=1e-3)
+
+
+def test_rootq_weight_backward_matches_autograd_of_the_reference_chain():
+    """Fused backward of the RootQ weight transform (gw, g_upper, g_lower, g_alpha) against autograd through the
+    reference's op chain on the device (pow / log: fp32 tolerance)."""
+    import math
+    from dlmc.quantization.scalar import kernels as K
+    from dlmc.quantization.scalar.RootQ import base as RB
+    g = torch.Generator().manual_seed(4242)
+    for shape, bits, alpha in (((64, 32, 3, 3), 4, 0.25), ((40, 24), 2, 0.7), ((16, 8, 3, 3), 3, 1.5), ((8, 16), 4, 5e-5)):
+        lo, hi = -(2 ** (bits - 1) - 1), 2 ** (bits - 1) - 1
+        w = (torch.randn(shape, generator=g) * 0.1).to(DEV)
+        gy = torch.randn(shape, generator=g).to(DEV)
+        bound = 2 * float(w.abs().mean()) * math.sqrt(hi)
+        leaves = [w.clone().requires_grad_(True)] + [torch.tensor(v, device=DEV, requires_grad=True) for v in (bound, -bound, alpha)]
+        RB._weight_composite(*leaves, lo, hi).backward(gy)
+        gw, gu, gl, ga = K.rootq_weight_backward(w, gy, leaves[1], leaves[2], leaves[3], lo, hi)
+        tag = f"rootq weight bwd {shape} b{bits} alpha {alpha}"
+        torch.testing.assert_close(gw, leaves[0].grad, rtol=2e-4, atol=2e-5, msg=lambda m: f"{tag} gw: {m}")
+        scale = float(gy.abs().sum())
+        for name, got, want in (("g_upper", gu, leaves[1].grad), ("g_lower", gl, leaves[2].grad), ("g_alpha", ga, leaves[3].grad)):
+            assert abs(float(got) - float(want)) <= 2e-4 * abs(float(want)) + 1e-5 * scale, f"{tag} {name}: {float(got)} vs {float(want)}"
+        # through the autograd Function of the wrapper
+        l2 = [w.clone().requires_grad_(True)] + [torch.tensor(v, device=DEV, requires_grad=True) for v in (bound, -bound, alpha)]
+        RB._RootQWeightFn.apply(*l2, lo, hi).backward(gy)
+        torch.testing.assert_close(l2[0].grad, leaves[0].grad, rtol=2e-4, atol=2e-5)
+        for a, b in zip(l2[1:], leaves[1:]):
+            assert abs(float(a.grad) - float(b.grad)) <= 2e-4 * abs(float(b.grad)) + 1e-5 * scale
