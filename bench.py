@@ -290,7 +290,9 @@ def main():
         "metric": "ResNet-50 W8A8 fake-quant fwd images/sec" if args.model == "resnet50" else f"{args.model} W8A8 fake-quant fwd images/sec",
         "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        # the arithmetic of the step: int8 x int8 -> int32 on the matrix cores with fp32 quantise / dequantise (int8 mode), or fp32
+        "dtype": "i8" if args.int8 else "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} W8A8 per-channel fake-quant forward (FSPTQ forms: W minmax_channel s8, "
                                f"A minmax_tensor u8), {'BatchNorm kept' if args.keep_bn else 'BN folded first as in FSPTQuant.py:67'}, "
                                f"{'fused int8 MFMA conv/linear' if args.int8 else 'fp32 conv of the fake-quantised operands'}, "
