@@ -193,6 +193,163 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
   }
 }
 
+// ------------------------------------------------------------------ first layer + 3x3/2 max-pool in one kernel
+// The ResNet stem: conv -> ReLU -> MaxPool2d(3, 2, 1) -> the next layers' quantiser.  Done separately the convolution has
+// to quantise and write all P x Q outputs (4x the pooled count; that epilogue, not the MFMAs, is its cost) and the pool
+// reads them back.  Here a workgroup owns a 3 x 8 tile of POOLED pixels: it convolves the 7 x 17 conv pixels under it
+// (1.24x recomputation at the tile seams; four 32-pixel MFMA tiles, one per wave), parks the
+// integer sums in LDS, max-pools THEM (the dequantisation is monotone per channel), and dequantises, rectifies and
+// quantises only the 24 pooled pixels: the same fp32 values and codes as ReLU -> max-pool -> fake-quant on the full map.
+constexpr int SP_TH = 3, SP_TW = 8;                       // pooled tile (7 x 17 = 119 conv pixels = 4 MFMA tiles: one per wave)
+constexpr int SP_RH = 2 * SP_TH + 1, SP_RW = 2 * SP_TW + 1;   // conv region under it (window 3, stride 2)
+constexpr int SP_NPIX = SP_RH * SP_RW;                    // 119
+constexpr int SP_TILES = (SP_NPIX + 31) / 32;             // 4
+constexpr int SP_LD = 68;
+
+struct StemPoolGeom {
+  int N, Hp, Wp, K, stride, P, Q, PP, QP, tiles_h, tiles_w;
+  uint32_t nwork;
+  FastDiv twdiv, thdiv;
+};
+
+
+template <int R>
+__global__ __launch_bounds__(256) void conv_stem_pool_i8_kernel(const uint8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                                float* __restrict__ out, const float* __restrict__ bias,
+                                                                const int32_t* __restrict__ wsum, const float* __restrict__ s_in,
+                                                                const float* __restrict__ zp_in, const float* __restrict__ s_w,
+                                                                StemPoolGeom g, int shift, ConvEpi ep) {
+  __shared__ __attribute__((aligned(16))) int region[SP_TILES * 32 * SP_LD];   // conv pixels x 64 channels: the int32 sums (+ corr)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hsel = lane >> 5;
+  const uint32_t xorw = shift ? 0x80808080u : 0u;
+  const float zpf = zp_in ? zp_in[0] : 0.0f;
+  const int zpi = (int)__builtin_rintf(zpf);
+  const float sin = s_in[0];
+  const EpiQuant eq(ep);
+  i32x4 bf[R][2];
+  float mult[2], bv[2];
+  int corr[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = j * 32 + (lane & 31);
+    const bool ok = k < g.K;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      bf[r][j] = ok ? *reinterpret_cast<const i32x4*>(w + ((int64_t)k * R + r) * 32 + hsel * 16) : i32x4{0, 0, 0, 0};
+    mult[j] = ok ? sin * s_w[k] : 0.0f;
+    corr[j] = ok ? (shift - zpi) * wsum[k] : 0;
+    bv[j] = (ok && bias) ? bias[k] : 0.0f;
+  }
+  const int rowbytes = g.Wp * 4;
+  // the pool phase dequantises channels c4 .. c4+3 of its pixels: their constants, once
+  float pm[4], pb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = (threadIdx.x & 15) * 4 + c;
+    pm[c] = k < g.K ? sin * s_w[k] : 0.0f;
+    pb[c] = (k < g.K && bias) ? bias[k] : 0.0f;
+  }
+  const bool anyneg = __ballot(mult[0] < 0.0f || mult[1] < 0.0f) != 0;
+  // persistent workgroups: the weight fragments above are loaded once, then (image, pooled tile) after tile; wave w owns
+  // conv tile w of every item, and its operand loads for the NEXT item are issued before this item's epilogue and pool
+  static_assert(SP_TILES == 4, "one conv tile per wave");
+  const int idx = wave * 32 + (lane & 31);
+  const int ry = idx / SP_RW, rx = idx - ry * SP_RW;
+  auto locate = [&](uint32_t work, uint32_t& n, int& th, int& tw, bool& valid) -> const uint8_t* {
+    const uint32_t t0 = fdiv(work, g.twdiv);
+    tw = (int)(work - t0 * (uint32_t)g.tiles_w);
+    n = fdiv(t0, g.thdiv);
+    th = (int)(t0 - n * (uint32_t)g.tiles_h);
+    const int p = 2 * th * SP_TH - 1 + ry, q = 2 * tw * SP_TW - 1 + rx;
+    valid = idx < SP_NPIX && p >= 0 && p < g.P && q >= 0 && q < g.Q;
+    const int pc = valid ? p : 0, qc = valid ? q : 0;            // an address that exists; the value is discarded
+    return x + (((int64_t)n * g.Hp + (int64_t)pc * g.stride) * g.Wp + (int64_t)qc * g.stride) * 4 + hsel * 16;
+  };
+  i32x4 af[R];
+  uint32_t n = 0, n_nx = 0;
+  int th = 0, tw = 0, th_nx = 0, tw_nx = 0;
+  bool valid = false, valid_nx = false;
+  if (blockIdx.x < g.nwork) {
+    const uint8_t* src = locate(blockIdx.x, n, th, tw, valid);
+#pragma unroll
+    for (int r = 0; r < R; ++r) af[r] = *reinterpret_cast<const i32x4*>(src + (int64_t)r * rowbytes);
+  }
+  for (uint32_t work = blockIdx.x; work < g.nwork; work += gridDim.x) {
+    i32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][i] = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const i32x4 a = i32x4{(int)(af[r].x ^ xorw), (int)(af[r].y ^ xorw), (int)(af[r].z ^ xorw), (int)(af[r].w ^ xorw)};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[r][j], acc[j], 0, 0, 0);
+    }
+    if (work + gridDim.x < g.nwork) {                // the next item's operands travel while this one is finished
+      const uint8_t* src = locate(work + gridDim.x, n_nx, th_nx, tw_nx, valid_nx);
+#pragma unroll
+      for (int r = 0; r < R; ++r) af[r] = *reinterpret_cast<const i32x4*>(src + (int64_t)r * rowbytes);
+    }
+    // which of this tile's pixels exist: row r of the accumulator is pixel wave*32 + r, owned by lane r of each half-wave
+    // What is parked in LDS is the exact integer sum a = acc + corr, not its dequantised value: v(a) = fl(fl(float(a)*m) + b)
+    // and ReLU are monotone in a for m >= 0, so max-pooling a and THEN dequantising the pooled quarter gives the same fp32
+    // values as pooling v - at one integer add per conv output instead of eight operations.  (m < 0 - a negative scale, which
+    // no observer of this library produces - flips the order: those channels store -a and are negated back after the pool.)
+    // Rows >= SP_NPIX of the last tile are never read by the pool, so only image borders need the validity mask: interior
+    // tiles - the vast majority - skip it on a wave-uniform branch.
+    const uint32_t vmask = (uint32_t)__ballot(valid || idx >= SP_NPIX);
+    const uint32_t vm = hsel ? (vmask >> 4) : vmask;           // bit (i&3) + 8(i>>2) = row r of this half-wave
+    int* dst = region + (wave * 32 + 4 * hsel) * SP_LD + (lane & 31);
+    if (vmask == 0xffffffffu && !anyneg) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * SP_LD + j * 32] = acc[j][i] + corr[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int a = acc[j][i] + corr[j];
+          if (mult[j] < 0.0f) a = -a;
+          if (!((vm >> ((i & 3) + 8 * (i >> 2))) & 1u)) a = INT32_MIN;     // outside the image: never wins the pool
+          dst[((i & 3) + 8 * (i >> 2)) * SP_LD + j * 32] = a;
+        }
+    }
+  __syncthreads();
+  // ---- pool 3x3 / 2 in fp32, then the consumer's quantiser on the pooled pixels: up to 2 float4 per thread ----
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int item = threadIdx.x + u * 256;
+    if (item >= SP_TH * SP_TW * 16) continue;
+    const int pp = item >> 4, c4 = (item & 15) * 4;
+    const int py = pp / SP_TW, px = pp - py * SP_TW;
+    const int ph = th * SP_TH + py, pw = tw * SP_TW + px;
+    if (ph >= g.PP || pw >= g.QP || c4 >= g.K) continue;
+    i32x4 am = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const i32x4 v = *reinterpret_cast<const i32x4*>(region + ((2 * py + dy) * SP_RW + 2 * px + dx) * SP_LD + c4);
+        am = i32x4{max(v.x, am.x), max(v.y, am.y), max(v.z, am.z), max(v.w, am.w)};
+      }
+    f32x4 m;
+    m.x = (float)(pm[0] < 0.0f ? -am.x : am.x) * pm[0] + pb[0];
+    m.y = (float)(pm[1] < 0.0f ? -am.y : am.y) * pm[1] + pb[1];
+    m.z = (float)(pm[2] < 0.0f ? -am.z : am.z) * pm[2] + pb[2];
+    m.w = (float)(pm[3] < 0.0f ? -am.w : am.w) * pm[3] + pb[3];
+    if (ep.relu) m = f32x4{relu_nan(m.x), relu_nan(m.y), relu_nan(m.z), relu_nan(m.w)};
+    const int64_t at = (((int64_t)n * g.PP + ph) * g.QP + pw) * g.K + c4;
+    if (out) __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(out + at));
+    if (ep.codes) __builtin_nontemporal_store(eq.code4(m), reinterpret_cast<uint32_t*>(ep.codes + at));
+  }
+  __syncthreads();     // the region is rewritten by the next item
+  n = n_nx; th = th_nx; tw = tw_nx; valid = valid_nx;
+  }
+}
+
 // ------------------------------------------------------------------------- max-pool on codes
 struct PoolGeom {
   int N, H, W, C4, k, stride, pad, P, Q;   // C4 = C / 4 (dwords per pixel)
@@ -371,3 +528,58 @@ extern "C" int dlmcq_maxpool_codes_nhwc(const void* x, void* y, int64_t N, int64
   else hipLaunchKernelGGL((maxpool_codes_kernel<1>), grid, dim3(DLMCQ_BLOCK), 0, st, static_cast<const uint32_t*>(x), static_cast<uint32_t*>(y), g, flip);
   return launch_status();
 }
+
+extern "C" int dlmcq_conv2d_i8_stem_pool_fused(const void* xpad, const int8_t* w, float* out, const float* bias,
+                                               const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                                               const float* w_scale, int64_t N, int64_t Hp, int64_t Wp, int64_t K, int64_t R,
+                                               int64_t S, int32_t stride, int32_t x_is_unsigned, int32_t relu, void* codes,
+                                               const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
+                                               int32_t q_form, float q_ste_g, dlmcq_stream_t stream) {
+  if (N < 0 || Hp < 1 || Wp < 1 || K < 4 || K > 64 || (K & 3) || R < 1 || R > ST_MAXR || S < 1 || S > 8 || stride < 1)
+    return DLMCQ_EINVAL;
+  if (Hp < R || Wp < S) return DLMCQ_EINVAL;
+  const int64_t P = (Hp - R) / stride + 1, Q = (Wp - S) / stride + 1;
+  const int64_t PP = (P + 2 - 3) / 2 + 1, QP = (Q + 2 - 3) / 2 + 1;     // MaxPool2d(3, 2, 1), floor mode
+  if (PP < 1 || QP < 1) return DLMCQ_EINVAL;
+  if (N == 0) return DLMCQ_OK;
+  if (!xpad || !w || !(out || codes) || !wsum || !in_scale || !w_scale) return DLMCQ_EINVAL;
+  if (codes && (!q_scale || q_lo > q_hi || q_lo < -128 || q_hi > 255 || q_hi - q_lo > 255 || q_form < DLMCQ_FORM_EMULATE ||
+                q_form > DLMCQ_FORM_SYMMETRIC))
+    return DLMCQ_EINVAL;
+  if (!aligned4(xpad) || !aligned16(w) || (out && !aligned16(out)) || (codes && !aligned4(codes))) return DLMCQ_EALIGN;
+  StemPoolGeom g;
+  g.N = (int)N; g.Hp = (int)Hp; g.Wp = (int)Wp; g.K = (int)K; g.stride = stride; g.P = (int)P; g.Q = (int)Q;
+  g.PP = (int)PP; g.QP = (int)QP;
+  g.tiles_h = (int)((PP + SP_TH - 1) / SP_TH);
+  g.tiles_w = (int)((QP + SP_TW - 1) / SP_TW);
+  const int64_t wgs = N * g.tiles_h * g.tiles_w;
+  if (wgs >= (1ll << 31) || N * Hp * Wp >= (1ll << 31)) return DLMCQ_ERANGE;
+  g.twdiv = make_fastdiv((uint32_t)g.tiles_w);
+  g.thdiv = make_fastdiv((uint32_t)g.tiles_h);
+  g.nwork = (uint32_t)wgs;
+  ConvEpi ep{};
+  ep.relu = relu != 0;
+  ep.codes = static_cast<uint8_t*>(codes);
+  ep.q_scale = q_scale;
+  ep.q_zp = q_zero_point;
+  ep.q_lo = (float)q_lo;
+  ep.q_hi = (float)q_hi;
+  ep.q_g = q_ste_g;
+  ep.q_form = q_form;
+  const int shift = x_is_unsigned ? 128 : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const uint8_t* xs = static_cast<const uint8_t*>(xpad);
+#define DLMCQ_SP_ARGS dim3((uint32_t)(wgs < 1024 ? wgs : 1024)), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep
+  switch ((int)R) {
+    case 1: hipLaunchKernelGGL((conv_stem_pool_i8_kernel<1>), DLMCQ_SP_ARGS); break;
+    case 2: hipLaunchKernelGGL((conv_stem_pool_i8_kernel<2>), DLMCQ_SP_ARGS); break;
+    case 3: hipLaunchKernelGGL((conv_stem_pool_i8_kernel<3>), DLMCQ_SP_ARGS); break;
+    case 4: hipLaunchKernelGGL((conv_stem_pool_i8_kernel<4>), DLMCQ_SP_ARGS); break;
+    case 5: hipLaunchKernelGGL((conv_stem_pool_i8_kernel<5>), DLMCQ_SP_ARGS); break;
+    case 6: hipLaunchKernelGGL((conv_stem_pool_i8_kernel<6>), DLMCQ_SP_ARGS); break;
+    default: hipLaunchKernelGGL((conv_stem_pool_i8_kernel<7>), DLMCQ_SP_ARGS); break;
+  }
+#undef DLMCQ_SP_ARGS
+  return launch_status();
+}
+

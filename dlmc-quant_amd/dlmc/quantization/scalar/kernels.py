@@ -454,13 +454,18 @@ def quantize_weight_stem(w, scale, lo, hi):
     return wq, wsum
 
 
-def conv2d_i8_stem(xpad, wq, wsum, bias, in_scale, in_zp, w_scale, S, stride=1, relu=False, emit=None, want_out=True):
+def conv2d_i8_stem(xpad, wq, wsum, bias, in_scale, in_zp, w_scale, S, stride=1, relu=False, emit=None, want_out=True, pool=False):
     """The first-layer convolution on padded NHWC4 codes (quantize_pad_nhwc4 / quantize_weight_stem).  Returns fp32
-    (N, K, P, Q) channels_last, or `(out, codes)` with `emit` (see conv2d_i8)."""
+    (N, K, P, Q) channels_last, or `(out, codes)` with `emit` (see conv2d_i8).  `pool=True` (K <= 64): followed by
+    MaxPool2d(3, 2, 1) in the same kernel - the results are the pooled tensors."""
     N.require_gpu(xpad, wq)
     n, hp, wp, _ = xpad.shape
     K_, R = wq.shape[0], wq.shape[1]
     P, Q = (hp - R) // stride + 1, (wp - S) // stride + 1
+    if pool:
+        if K_ > 64:
+            raise ValueError("conv2d_i8_stem(pool=True) handles at most 64 output channels")
+        P, Q = (P + 2 - 3) // 2 + 1, (Q + 2 - 3) // 2 + 1
     if not want_out and emit is None:
         raise ValueError("conv2d_i8_stem: nothing to produce (want_out=False without emit)")
 
@@ -483,7 +488,7 @@ def conv2d_i8_stem(xpad, wq, wsum, bias, in_scale, in_zp, w_scale, S, stride=1, 
         lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
     oe = n * K_ * P * Q
     PROFILE.launch("conv_stem", xpad.numel() + wq.numel() + oe * (4 * want_out + (emit is not None)),
-                   lambda: N.check(N.lib.dlmcq_conv2d_i8_stem_fused(
+                   lambda: N.check((N.lib.dlmcq_conv2d_i8_stem_pool_fused if pool else N.lib.dlmcq_conv2d_i8_stem_fused)(
                        N.ptr(xpad), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),
                        n, hp, wp, K_, R, int(S), int(stride), int(xpad.dtype == torch.uint8), int(bool(relu)), N.ptr(out_codes),
                        N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())))

@@ -235,10 +235,11 @@ class StemLayer(_PlanLayer):
         xpad = K.quantize_pad_nhwc4(x, act.scale, act.zp, act.lo, act.hi, act.form, pad, g=act.g(numel))
         k, _, r, s = lay.weight.shape
         emit = self._emit_for(x.shape[0], k, (x.shape[2] + 2 * pad - r) // st + 1, (x.shape[3] + 2 * pad - s) // st + 1)
+        in_kernel = self.pool == (3, 2, 1) and k <= 64      # conv + ReLU + MaxPool2d(3, 2, 1) + quantiser: one kernel
         res = K.conv2d_i8_stem(xpad, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale, s, stride=st,
-                               relu=self.relu, emit=emit, want_out=self.want_out)
+                               relu=self.relu, emit=emit, want_out=self.want_out, pool=in_kernel)
         out, out_codes = res if emit is not None else (res, None)
-        return self._finish(out, out_codes)
+        return (out, out_codes) if in_kernel else self._finish(out, out_codes)
 
 
 class _DryNode(nn.Module):
@@ -368,7 +369,10 @@ def fuse_inference(model, report=None, dry_run=False):
         if len(users) == 1 and _pool_params(users[0], modules) is not None and modules[node.target].weight.shape[0] % 4 == 0:
             mp = users[0]
             cons = [accepts(u, mp) for u in mp.users]
-            if cons and all(c is not None for c in cons) and len({c.key for c in cons}) == 1:
+            on_codes = cons and all(c is not None for c in cons) and len({c.key for c in cons}) == 1
+            # the first-layer kernel pools in fp32 itself (any consumers); elsewhere the pool runs on the emitted codes
+            in_stem = spec[4] == "stem" and _pool_params(mp, modules) == (3, 2, 1) and modules[node.target].weight.shape[0] <= 64
+            if on_codes or in_stem:
                 pool = _pool_params(mp, modules)
                 chain.append(mp)
                 last = mp

@@ -352,6 +352,19 @@ int dlmcq_conv2d_i8_stem_fused(const void* xpad, const int8_t* w, float* out, co
                                int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
 
 /*
+ * dlmcq_conv2d_i8_stem_fused followed by ReLU (if asked) and nn.MaxPool2d(3, 2, 1) in ONE kernel, K <= 64: out / codes
+ * are the POOLED tensor [N, (P+1)/2.., (Q+1)/2.., K].  The pool runs on the fp32 values (the reference's order: ReLU,
+ * max-pool, fake-quant; NaN propagates as in torch), so only the pooled quarter of the outputs is quantised and
+ * nothing un-pooled is ever written.
+ */
+int dlmcq_conv2d_i8_stem_pool_fused(const void* xpad, const int8_t* w, float* out, const float* bias,
+                                    const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                                    const float* w_scale, int64_t N, int64_t Hp, int64_t Wp, int64_t K, int64_t R,
+                                    int64_t S, int32_t stride, int32_t x_is_unsigned, int32_t relu, void* codes,
+                                    const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
+                                    int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
+
+/*
  * nn.MaxPool2d (square window, dilation 1, floor mode) on NHWC activation codes.  The quantisers of this library
  * are monotone, so  code(maxpool(v)) == maxpool(code(v)):  pooling the 1-byte codes replaces pooling the fp32
  * tensor and quantising the result.  C % 4 == 0; padding never wins (torch pads with -inf).

@@ -193,7 +193,7 @@ def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res, sign
     elif arch == "resnet18" and qtype == "FSPTQ":
         assert rep.stem == 0 and rep.skipped == ["conv1"]       # non-integer zero point: fp32 first layer
     if arch == "resnet18" and qtype is None:
-        assert rep.stem == 1 and rep.pooled == 0                # QBase: signed codes, zero offset; this pool also feeds a shortcut
+        assert rep.stem == 1 and rep.pooled == 1                # QBase: signed codes; the stem kernel pools in fp32, shortcut included
     # and under a HIP graph
     from dlmc.utils.graph import GraphedForward
     fwd = GraphedForward(fused, x)
@@ -260,6 +260,45 @@ def test_stem_kernels_match_the_generic_path(unsigned):
         none, codes2 = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=stride, relu=True, emit=emit, want_out=False)
         assert none is None
         same(codes2, wc, f"stem case {idx} codes-only")
+
+
+def test_stem_with_the_pool_inside():
+    """conv -> ReLU -> MaxPool2d(3, 2, 1) -> quantiser as one kernel against the separate ops (bit for bit; NaN wins)."""
+    import torch.nn.functional as F
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    for idx, (n, c, h, w, k, r, s, stride, pad) in enumerate([(2, 3, 32, 32, 64, 7, 7, 2, 3), (3, 3, 17, 23, 64, 3, 3, 2, 1),
+                                                               (1, 4, 13, 9, 32, 5, 5, 1, 2), (2, 1, 7, 50, 8, 1, 3, 1, 0),
+                                                               (5, 3, 9, 9, 64, 3, 3, 1, 1)]):
+        gg = gen(600 + idx)
+        x = torch.randn(n, c, h, w, generator=gg).to(DEV)
+        if idx == 1:
+            x.view(-1)[123] = float("nan")
+        s_in = torch.tensor([float(x[torch.isfinite(x)].abs().max()) / 120], device=DEV)
+        zp = torch.tensor([128.0], device=DEV)
+        wt = (torch.randn(k, c, r, s, generator=gg) * 0.1).to(DEV)
+        s_w = wt.abs().amax(dim=(1, 2, 3)) / 127 + 1e-6
+        if idx == 4:
+            s_w[5] = -s_w[5]          # a negative scale (no observer produces one): the pool's order flips for that channel
+            s_w[33] = -s_w[33]
+        bias = torch.randn(k, generator=gg).to(DEV)
+        xpad = K.quantize_pad_nhwc4(x, s_in, zp, 0, 255, N.FORM_ZEROPOINT, pad)
+        wq, wsum = K.quantize_weight_stem(wt, s_w, -127, 127)
+        for relu in (True, False):
+            conv = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=stride, relu=relu)
+            want = F.max_pool2d(conv, 3, 2, 1)
+            q_s = torch.tensor([float(want[torch.isfinite(want)].abs().max()) / 255 * 0.9 + 1e-3], device=DEV)
+            emit = K.EmitCodes(q_s, torch.tensor([7.0], device=DEV), 0, 255, N.FORM_ZEROPOINT)
+            _, wc = K.fake_quant(want, q_s, emit.zero_point, 0, 255, N.FORM_ZEROPOINT, codes="i8", want_y=False)
+            out, codes = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=stride, relu=relu, emit=emit, pool=True)
+            assert out.shape == want.shape and out.is_contiguous(memory_format=torch.channels_last)
+            nan = torch.isnan(want)
+            assert torch.equal(torch.isnan(out), nan), f"pooled stem {idx}: NaN pattern"
+            same(torch.where(nan, torch.zeros_like(out), out), torch.where(nan, torch.zeros_like(want), want), f"pooled stem {idx} relu={relu} out")
+            same(codes, wc, f"pooled stem {idx} relu={relu} codes")
+            none, c2 = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=stride, relu=relu, emit=emit, want_out=False, pool=True)
+            assert none is None
+            same(c2, wc, f"pooled stem {idx} codes-only")
 
 
 @pytest.mark.parametrize("dtype", [torch.uint8, torch.int8])

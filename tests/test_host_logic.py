@@ -179,7 +179,7 @@ def test_fusion_decisions_without_a_gpu():
     rep = fuse_inference(calibrated(W.resnet50(), first_layer_zp=-2.117), dry_run=True).fusion_report
     assert rep.stem == 0 and rep.skipped == ["conv1"] and rep.layers == 53       # non-integer zero point: fp32 first layer
     rep = fuse_inference(calibrated(W.resnet18()), dry_run=True).fusion_report
-    assert (rep.layers, rep.stem, rep.pooled, rep.dual, rep.residual) == (21, 1, 0, 3, 8)   # the pool also feeds a shortcut
+    assert (rep.layers, rep.stem, rep.pooled, rep.dual, rep.residual) == (21, 1, 1, 3, 8)   # the stem kernel pools in fp32: shortcut served too
     rep = fuse_inference(calibrated(W.repvgg_a1_deploy()), dry_run=True).fusion_report
     assert (rep.layers, rep.stem, rep.relu, rep.emit, rep.fp32_outputs, rep.dual) == (23, 1, 22, 21, 2, 0)
     rep = fuse_inference(calibrated(W.mobileone_s1_deploy()), dry_run=True).fusion_report
