@@ -1,0 +1,72 @@
+// Definitions shared by the int8 convolution translation units (conv_i8.hip, conv_i8_pp.hip).  Not part of the ABI.
+#pragma once
+
+#include <type_traits>
+
+#include "dlmcq_internal.h"
+#include "conv_epilogue.h"
+
+namespace dlmcq {
+
+constexpr int CV_BM = 128;
+constexpr int CV_BK = 64;
+constexpr int CV_LD = CV_BK + 16;  // LDS row stride in bytes
+
+struct ConvGeom {
+  int N, H, W, C, K, R, S, stride, pad, dil, P, Q;
+  int64_t M;          // N*P*Q (< 2^31)
+  int nblk_m, nblk_n;
+  FastDiv qdiv, pdiv; // row index -> (n, p, q) without 64-bit divisions
+};
+
+// output row m -> image n and the top-left input coordinate of its receptive field
+__device__ __forceinline__ void row_origin(const ConvGeom& g, uint32_t m, int& n, int& h0, int& w0) {
+  const uint32_t t = fdiv(m, g.qdiv);
+  const int q = (int)(m - t * (uint32_t)g.Q);
+  const uint32_t nn = fdiv(t, g.pdiv);
+  const int p = (int)(t - nn * (uint32_t)g.P);
+  n = (int)nn;
+  h0 = p * g.stride - g.pad;
+  w0 = q * g.stride - g.pad;
+}
+
+struct PadTable {   // 64 bytes of every byte value: a padded tap reads its K chunks at offsets 0 / 32 of one line
+  int8_t b[256 * 64];
+  constexpr PadTable() : b() {
+    for (int v = 0; v < 256; ++v)
+      for (int j = 0; j < 64; ++j) b[v * 64 + j] = (int8_t)v;
+  }
+};
+static __device__ const PadTable g_pad_table = PadTable();
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+
+struct ConvSeg2 {
+  const int8_t* x;
+  const int8_t* w;
+  const float* bias;
+  const int32_t* wsum;
+  const float* s_in;
+  const float* zp_in;
+  const float* s_w;
+  ConvGeom g;
+  int shift;
+};
+
+// A 16-byte global load the compiler does not know about (no s_waitcnt is generated for it: the caller counts vmcnt)
+template <int OFF>
+__device__ __forceinline__ void gload16(i32x4& dst, const int8_t* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+}  // namespace dlmcq

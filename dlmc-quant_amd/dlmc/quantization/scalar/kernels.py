@@ -293,7 +293,7 @@ class EmitCodes:
         return torch.uint8 if self.lo >= 0 else torch.int8
 
 
-def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1, variant=None,
+def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1,
               residual=None, relu=False, emit=None, want_out=True):
     """Fused int8 conv / linear on the matrix cores.  `codes`: uint8/int8 activation codes, logically
     (N, C, H, W) in channels_last memory, or (N, C) for a linear layer.  Returns fp32 (N, K, P, Q) in
@@ -335,8 +335,6 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
             n, h, w_, c, K, R, S, int(stride), int(padding), int(dilation), int(codes.dtype == torch.uint8))
     out_elems = n * K * P * Q
     if fused:
-        if variant is not None:
-            raise ValueError("conv2d_i8: the epilogue options exist only in the default kernel")
         out_codes = q_scale = q_zp = None
         lo = hi = form = 0
         g = 0.0
@@ -359,11 +357,7 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
             N.stream_ptr())))
         return (out, out_codes) if emit is not None else out
     args = args + (N.stream_ptr(),)
-    if variant is None:
-        PROFILE.launch("conv_i8", codes.numel() + out_elems * 4 + wq.numel(),
-                       lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(*args)))
-    else:   # test / tuning hook outside the ABI
-        N.check(N.experimental("dlmcq_x_conv2d_i8_variant", N.SIGNATURES["dlmcq_conv2d_i8_nhwc_f32"][1] + [N._i32])(*args, int(variant)))
+    PROFILE.launch("conv_i8", codes.numel() + out_elems * 4 + wq.numel(), lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(*args)))
     return out
 
 

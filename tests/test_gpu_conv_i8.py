@@ -25,33 +25,6 @@ CASES = [  # N, C, H, W, K, R, stride, pad, dil
 ]
 
 
-CASES_BIG = [(2, 64, 260, 260, 128, 3, 1, 1, 1)]   # M = 135 200 rows: reaches the 256-row tiles of variant 3
-
-
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 16, 17])
-def test_conv_i8_kernel_variants(variant):
-    """Every kernel variant (0 register-staged, 1 default dispatch, 2 LDS-DMA 128-row only, 3 256-row tiles,
-    4 wave-specialised 128-row, 9 wave-specialised 256-row forced) on every shape."""
-    from dlmc.quantization.scalar import kernels as K
-    for idx, (n, c, h, w, k, r, stride, pad, dil) in enumerate(CASES + (CASES_BIG if variant in (1, 3, 8, 9, 16, 17) else [])):
-        g = gen(idx)
-        codes = torch.randint(0, 256, (n, c, h, w), generator=g).to(torch.uint8)
-        wt = torch.randn(k, c, r, r, generator=g) * 0.05
-        s_w, _ = O.minmax_channel(wt, 8, True, ch_axis=0)
-        bias = torch.randn(k, generator=g)
-        wq, wsum = K.quantize_weight_krsc(wt.to(DEV), s_w.to(DEV), -127, 127)
-        cd = codes.to(DEV).contiguous(memory_format=torch.channels_last)
-        kw = dict(stride=stride, padding=pad, dilation=dil)
-        if idx < len(CASES):
-            ref = F.conv2d((codes.double() - 2.0) * 0.0173, O.fq_symmetric(wt, s_w, -127, 127)[1].double(), bias.double(), **kw)
-        else:   # too big for a float64 CPU conv: the default variant on the same data is the reference
-            ref = K.conv2d_i8(cd, wq, wsum, bias.to(DEV), torch.tensor(0.0173, device=DEV), torch.tensor(2.0, device=DEV),
-                              s_w.to(DEV), variant=0, **kw).cpu().double()
-        got = K.conv2d_i8(cd, wq, wsum, bias.to(DEV), torch.tensor(0.0173, device=DEV), torch.tensor(2.0, device=DEV),
-                          s_w.to(DEV), variant=variant, **kw)
-        torch.testing.assert_close(got.cpu().double(), ref, rtol=2e-6, atol=2e-5, msg=lambda m: f"variant {variant} case {idx}: {m}")
-
-
 @pytest.mark.parametrize("unsigned", [True, False])
 def test_conv_i8_matches_float64_reference(unsigned):
     from dlmc.quantization.scalar import kernels as K
