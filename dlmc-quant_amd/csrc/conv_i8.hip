@@ -413,9 +413,9 @@ static ConvPlan conv_plan(int64_t C, int64_t K, int64_t R, int64_t S, bool dual)
   p.bn = (dual_short || K <= 64 || (K % 128) != 0) ? 64 : 128;
   // (128 x 256 tiles - a third fewer operand bytes per MAC - gained 10-17 % on the 7x7 stage of the module path only and
   //  lost 40 % wherever the epilogue is fused: two workgroups per CU cannot hide a tile's latency chain.  Not built.)
-  // 1x1 reductions of >= 256 channels into <= 256: both operands through the ring, 64-wide tiles (full-line DMA reads of
+  // long 1x1 reductions (>= 512 channels, or 256 into 64): both operands through the ring, 64-wide tiles (full-line DMA reads of
   // the long activation rows beat fragment-shaped loads: 5-15 % on ResNet-50's 256->64 ... 2048->512 layers)
-  if (R * S == 1 && C >= 256 && K <= 256 && !dual && K % 64 == 0) {
+  if (R * S == 1 && !dual && K % 64 == 0 && ((C >= 512 && K <= 512) || (C >= 256 && K <= 64))) {
     p.bn = 64;
     p.adir = false;
   } else {

@@ -29,22 +29,12 @@ struct ImgGeom {
 };
 
 __global__ __launch_bounds__(DLMCQ_BLOCK) void quantize_pad_nhwc4_kernel(const float* __restrict__ x, uint32_t* __restrict__ out,
-                                                                         const float* __restrict__ scale,
-                                                                         const float* __restrict__ zp, ImgGeom g, float lo,
-                                                                         float hi, int form, float ste_g) {
-  const float s = scale[0], z = zp ? zp[0] : 0.0f;
-  const float dv = form == DLMCQ_FORM_EMULATE ? s + 1e-7f : (form == DLMCQ_FORM_QBASE ? ste_scale(s, ste_g) : s);
-  const float of = (form == DLMCQ_FORM_EMULATE || form == DLMCQ_FORM_QBASE) ? z : 0.0f;
-  const float zadd = form == DLMCQ_FORM_ZEROPOINT ? z : 0.0f;
-  auto code = [&](float v) -> uint32_t {   // fq_one, form by form (the STE identity matters for +-inf)
-    float q;
-    if (form == DLMCQ_FORM_EMULATE) q = clamp_nan(__builtin_rintf((v - of) / dv), lo, hi);
-    else if (form == DLMCQ_FORM_QBASE) q = ste_round(clamp_nan((v - of) / dv, lo, hi));
-    else if (form == DLMCQ_FORM_ZEROPOINT) q = clamp_nan(ste_round(v / dv) + zadd, lo, hi);
-    else q = clamp_nan(ste_round(v / dv), lo, hi);
-    return (uint32_t)(code_of(q) & 0xff);
-  };
-  const uint32_t border = code(0.0f) * 0x01010101u;   // x' = 0 (zero padding of the fake-quantised image) in every channel
+                                                                         ImgGeom g, ConvEpi q) {
+  // the quantiser is EpiQuant::code4 (conv_epilogue.h): the four forms' arithmetic at ~10 operations per element instead of
+  // a correctly rounded division each (this kernel was bound by them, not by HBM), bit-identical codes
+  const EpiQuant eq(q);
+  const uint32_t border = eq.code4(f32x4{0.0f, 0.0f, 0.0f, 0.0f});   // x' = 0 (zero padding of the fake-quantised image) in every channel
+  const uint32_t keep = g.C >= 4 ? 0xffffffffu : (1u << (8 * g.C)) - 1u;   // bytes of channels that do not exist stay 0
   const int64_t total = (int64_t)g.N * g.Hp * g.Wp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t t = fdiv((uint32_t)i, g.wdiv);
@@ -55,10 +45,14 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void quantize_pad_nhwc4_kernel(const f
     uint32_t px = border;
     if (h >= 0 && h < g.H && w >= 0 && w < g.W) {
       const float* p = x + (int64_t)n * g.sn + (int64_t)h * g.sh + (int64_t)w * g.sw;
-      px = 0;
-      for (int c = 0; c < g.C; ++c) px |= code(p[c * g.sc]) << (8 * c);
+      f32x4 v;
+      v.x = p[0];
+      v.y = g.C > 1 ? p[g.sc] : 0.0f;
+      v.z = g.C > 2 ? p[2 * g.sc] : 0.0f;
+      v.w = g.C > 3 ? p[3 * g.sc] : 0.0f;
+      px = eq.code4(v) & keep;
     }
-    out[i] = px;
+    __builtin_nontemporal_store(px, out + i);
   }
 }
 
@@ -243,11 +237,13 @@ __global__ __launch_bounds__(256) void conv_stem_pool_i8_kernel(const uint8_t* _
   const int rowbytes = g.Wp * 4;
   // the pool phase dequantises channels c4 .. c4+3 of its pixels: their constants, once
   float pm[4], pb[4];
+  int pc[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int k = (threadIdx.x & 15) * 4 + c;
     pm[c] = k < g.K ? sin * s_w[k] : 0.0f;
     pb[c] = (k < g.K && bias) ? bias[k] : 0.0f;
+    pc[c] = k < g.K ? (shift - zpi) * wsum[k] : 0;
   }
   const bool anyneg = __ballot(mult[0] < 0.0f || mult[1] < 0.0f) != 0;
   // persistent workgroups: the weight fragments above are loaded once, then (image, pooled tile) after tile; wave w owns
@@ -305,14 +301,15 @@ __global__ __launch_bounds__(256) void conv_stem_pool_i8_kernel(const uint8_t* _
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * SP_LD + j * 32] = acc[j][i] + corr[j];
+        for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * SP_LD + j * 32] = acc[j][i];
     } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          int a = acc[j][i] + corr[j];
+          int a = acc[j][i] + corr[j];      // (negated below: the constant must be inside)
           if (mult[j] < 0.0f) a = -a;
+          else a = acc[j][i];
           if (!((vm >> ((i & 3) + 8 * (i >> 2))) & 1u)) a = INT32_MIN;     // outside the image: never wins the pool
           dst[((i & 3) + 8 * (i >> 2)) * SP_LD + j * 32] = a;
         }
@@ -327,19 +324,23 @@ __global__ __launch_bounds__(256) void conv_stem_pool_i8_kernel(const uint8_t* _
     const int py = pp / SP_TW, px = pp - py * SP_TW;
     const int ph = th * SP_TH + py, pw = tw * SP_TW + px;
     if (ph >= g.PP || pw >= g.QP || c4 >= g.K) continue;
-    i32x4 am = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+    i32x4 rmax[3];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const i32x4 v = *reinterpret_cast<const i32x4*>(region + ((2 * py + dy) * SP_RW + 2 * px + dx) * SP_LD + c4);
-        am = i32x4{max(v.x, am.x), max(v.y, am.y), max(v.z, am.z), max(v.w, am.w)};
-      }
+    for (int dy = 0; dy < 3; ++dy) {     // three-operand maxima (v_max3_i32): 4 instead of 8 per channel
+      const int* rowp = region + ((2 * py + dy) * SP_RW + 2 * px) * SP_LD + c4;
+      const i32x4 v0 = *reinterpret_cast<const i32x4*>(rowp), v1 = *reinterpret_cast<const i32x4*>(rowp + SP_LD),
+                  v2 = *reinterpret_cast<const i32x4*>(rowp + 2 * SP_LD);
+      rmax[dy] = i32x4{max(max(v0.x, v1.x), v2.x), max(max(v0.y, v1.y), v2.y), max(max(v0.z, v1.z), v2.z), max(max(v0.w, v1.w), v2.w)};
+    }
+    i32x4 am = i32x4{max(max(rmax[0].x, rmax[1].x), rmax[2].x), max(max(rmax[0].y, rmax[1].y), rmax[2].y),
+                     max(max(rmax[0].z, rmax[1].z), rmax[2].z), max(max(rmax[0].w, rmax[1].w), rmax[2].w)};
+    // the per-channel constant (shift - zp) * SUM qw commutes with the maximum: added to the pooled quarter only (channels
+    // with a negative scale carry it inside, negated, and are negated back here)
     f32x4 m;
-    m.x = (float)(pm[0] < 0.0f ? -am.x : am.x) * pm[0] + pb[0];
-    m.y = (float)(pm[1] < 0.0f ? -am.y : am.y) * pm[1] + pb[1];
-    m.z = (float)(pm[2] < 0.0f ? -am.z : am.z) * pm[2] + pb[2];
-    m.w = (float)(pm[3] < 0.0f ? -am.w : am.w) * pm[3] + pb[3];
+    m.x = (float)(pm[0] < 0.0f ? -am.x : am.x + pc[0]) * pm[0] + pb[0];
+    m.y = (float)(pm[1] < 0.0f ? -am.y : am.y + pc[1]) * pm[1] + pb[1];
+    m.z = (float)(pm[2] < 0.0f ? -am.z : am.z + pc[2]) * pm[2] + pb[2];
+    m.w = (float)(pm[3] < 0.0f ? -am.w : am.w + pc[3]) * pm[3] + pb[3];
     if (ep.relu) m = f32x4{relu_nan(m.x), relu_nan(m.y), relu_nan(m.z), relu_nan(m.w)};
     const int64_t at = (((int64_t)n * g.PP + ph) * g.QP + pw) * g.K + c4;
     if (out) __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(out + at));
@@ -434,9 +435,16 @@ extern "C" int dlmcq_quantize_pad_nhwc4(const float* x, void* out, const float* 
   g.wdiv = make_fastdiv((uint32_t)g.Wp);
   g.hdiv = make_fastdiv((uint32_t)g.Hp);
   const int64_t blocks = (total + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
-  hipLaunchKernelGGL(quantize_pad_nhwc4_kernel, dim3((uint32_t)(blocks < 16384 ? blocks : 16384)), dim3(DLMCQ_BLOCK), 0,
-                     reinterpret_cast<hipStream_t>(stream), x, static_cast<uint32_t*>(out), scale, zero_point, g, (float)lo,
-                     (float)hi, form, ste_g);
+  ConvEpi q{};                          // the image quantiser, evaluated by EpiQuant (needs a non-null `codes` to resolve)
+  q.codes = static_cast<uint8_t*>(out);
+  q.q_scale = scale;
+  q.q_zp = zero_point;
+  q.q_lo = (float)lo;
+  q.q_hi = (float)hi;
+  q.q_g = ste_g;
+  q.q_form = form;
+  hipLaunchKernelGGL(quantize_pad_nhwc4_kernel, dim3((uint32_t)(blocks < 65536 ? blocks : 65536)), dim3(DLMCQ_BLOCK), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, static_cast<uint32_t*>(out), g, q);
   return launch_status();
 }
 

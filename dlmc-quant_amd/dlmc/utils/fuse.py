@@ -232,10 +232,10 @@ class StemLayer(_PlanLayer):
         lay, act = self.layer, self.act
         numel = x.numel()
         pad, st = lay.padding[0], lay.stride[0]
-        xpad = K.quantize_pad_nhwc4(x, act.scale, act.zp, act.lo, act.hi, act.form, pad, g=act.g(numel))
         k, _, r, s = lay.weight.shape
         emit = self._emit_for(x.shape[0], k, (x.shape[2] + 2 * pad - r) // st + 1, (x.shape[3] + 2 * pad - s) // st + 1)
         in_kernel = self.pool == (3, 2, 1) and k <= 64      # conv + ReLU + MaxPool2d(3, 2, 1) + quantiser: one kernel
+        xpad = K.quantize_pad_nhwc4(x, act.scale, act.zp, act.lo, act.hi, act.form, pad, g=act.g(numel))
         res = K.conv2d_i8_stem(xpad, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale, s, stride=st,
                                relu=self.relu, emit=emit, want_out=self.want_out, pool=in_kernel)
         out, out_codes = res if emit is not None else (res, None)
