@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: ResNet-50 W8A8 per-channel fake-quant forward (BASELINE.json configs[2]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling strong]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one forward of the quantised ResNet-50 (54 layers: fake-quant(input) [HIP], fake-quant(weight)
-[HIP], conv/linear [MIOpen/rocBLAS], plus the network's BN/ReLU/pool glue) over a batch of 512 synthetic
-224x224 images per GPU, scales frozen (the observer pass runs in the warm-up).  Activations and weights
-are resident in HBM when the timed region starts.  Weak scaling: every rank runs its own 512 images, no
-collective in the steady state (the observer all-reduce happens once, in the first warm-up step).
+A step = one forward of the quantised ResNet-50 (54 quantised layers, FSPTQ forms: weights minmax_channel s8, activations
+minmax_tensor u8, BatchNorm folded first as FSPTQuant.py:67 does) over 512 synthetic 224x224 images per GPU, scales frozen
+(the observer pass and its all-reduce run once, before the timed region).  Default mode = the frozen execution plan of
+dlmc/utils/fuse.py: every layer is ONE launch of the int8 MFMA kernel (csrc/conv_i8.hip) whose epilogue dequantises, adds
+the shortcut, applies ReLU and emits the NEXT layer's activation codes; weight codes are quantised once, when the plan is
+built (the reference re-quantises 0.2 GB of weights per forward: 0.5 % of the step's bytes).  `--plan modules` and
+`--conv fp32` run the reference's own op sequence (stand-alone fake-quant kernels + MIOpen convolutions).
+Inputs are resident in HBM when the timed region starts.  Weak scaling by default (512 images on every GPU, no collective
+in the steady state); `--scaling strong` splits a fixed global batch of 4096.
 
 One JSON line on rank 0.  Besides the contract fields:
-  roofline      the dominant kernel of the path - the per-tensor activation fake-quant (fq_tensor_kernel):
-                algorithmic bytes (8 B per element) / HIP-event duration, summed over its launches in the
-                timed region, on the launch stream
-  cpu_baseline  the CPU port of the same layer stack (oracle/), timed on this box's host cores on a
-                bounded sample (N = 1 only)
-  quant_path    images/s and GB/s of the fake-quant kernels alone (the HBM-bound part this project owns)
+  roofline             the kernel with the largest share of the step (the int8 MFMA kernel with its fused epilogue):
+                       algorithmic bytes / HIP-event durations of its launches in the first timed step, on the launch stream;
+                       `traffic` comes from the committed rocprofv3 PMC passes of the same command (`traffic_measured_in_run`
+                       says so: counters cannot be read from inside the process)
+  roofline_fake_quant  the stand-alone fake-quant kernel, measured live on BASELINE configs[1]'s tensor
+  cpu_baseline         the CPU port of the same layer stack (oracle/), timed on this box's host cores on a bounded sample
+                       (N = 1 only): all granted cores and one thread, median and min
 """
 import argparse
 import json
@@ -55,8 +60,9 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(batch, budget_s=20.0, fold_bn=True, halfnormal=True):
-    """The reference's CPU path (port in oracle/ref_layers.py) on a bounded sample of the same workload."""
+def cpu_baseline(batch, budget_s=16.0, fold_bn=True, halfnormal=True):
+    """The reference's CPU path (port in oracle/ref_layers.py) on a bounded sample of the same workload: all granted
+    cores (the headline `value`, from the median forward) and one thread, median and min of the timed forwards."""
     import workloads as W
     from oracle.ref_layers import port_model
     cores = usable_cores()
@@ -78,19 +84,27 @@ def cpu_baseline(batch, budget_s=20.0, fold_bn=True, halfnormal=True):
     x = torch.randn(batch, 3, 224, 224)
     if halfnormal:
         x = torch.relu(x)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        model(x)                      # calibration + warm-up
-        first = time.perf_counter() - t0
-        reps, spent = 0, 0.0
-        while reps < 1 or (spent + spent / reps < budget_s - first and reps < 50):
+
+    def timed(budget, max_reps):
+        ts = []
+        while not ts or (sum(ts) + sum(ts) / len(ts) < budget and len(ts) < max_reps):
             t0 = time.perf_counter()
             model(x)
-            spent += time.perf_counter() - t0
-            reps += 1
-    return {"value": round(batch * reps / spent, 2), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} forwards of batch {batch} (same ResNet-50 W8A8 layer stack, torch {torch.__version__} CPU, "
-                      f"{cores} threads), after 1 calibration forward"}
+            ts.append(time.perf_counter() - t0)
+        return ts
+    with torch.no_grad():
+        model(x)                      # calibration + warm-up
+        ts = timed(budget_s, 50)
+        torch.set_num_threads(1)
+        t1 = timed(budget_s / 2, 5)
+        torch.set_num_threads(cores)
+    med, med1 = statistics.median(ts), statistics.median(t1)
+    return {"value": round(batch / med, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{len(ts)} forwards of batch {batch} (same ResNet-50 W8A8 layer stack, torch {torch.__version__} CPU, "
+                      f"{cores} threads), after 1 calibration forward; value = batch / median forward time",
+            "median_ms": round(med * 1e3, 1), "min_ms": round(min(ts) * 1e3, 1),
+            "one_thread": {"value": round(batch / med1, 2), "median_ms": round(med1 * 1e3, 1), "min_ms": round(min(t1) * 1e3, 1),
+                           "forwards": len(t1)}}
 
 
 def main():
@@ -98,7 +112,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --batch images on every GPU; strong: a fixed global batch (--global-batch, default 4096 = "
+                         "BASELINE configs[3]'s 8 x 512) split evenly over the ranks")
+    ap.add_argument("--global-batch", type=int, default=4096, help="--scaling strong: images per step over all GPUs")
     ap.add_argument("--model", default="resnet50", choices=["resnet18", "resnet50", "repvgg_a1"])
     ap.add_argument("--keep-bn", action="store_true",
                     help="skip the BN folding of the reference's few-shot PTQ flow (FSPTQuant.py:67) and keep BatchNorm layers")
@@ -132,6 +150,9 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if args.scaling == "strong":
+        assert args.global_batch % world == 0, "--global-batch must be a multiple of the number of GPUs"
+        args.batch = args.global_batch // world
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -246,18 +267,19 @@ def main():
     # `roofline` describes the kernel of this project with the largest share of the timed region
     if conv["ms"] > fq["ms"]:
         if args.fused:
-            main_roof = roof("conv_i8", conv, "conv_i8_dma_kernel (int8 implicit-GEMM conv/linear; epilogue: dequant + residual + ReLU + "
+            main_roof = roof("conv_i8", conv, "conv_i8_mfma_kernel (int8 implicit-GEMM conv/linear; epilogue: dequant + residual + ReLU + "
                                               "next layer's activation codes)",
                              "algorithmic bytes per launch = int8 input + int8 weights + what the epilogue moves (1 B/elem codes, "
                              "4 B/elem fp32 output where a shortcut / pool needs it, 4 B/elem residual read)", ops=conv_ops)
         else:
-            main_roof = roof("conv_i8", conv, "conv_i8_dma_kernel (fused int8-dequant x GEMM conv/linear, fp32 NHWC out)",
+            main_roof = roof("conv_i8", conv, "conv_i8_mfma_kernel (fused int8-dequant x GEMM conv/linear, fp32 NHWC out)",
                              "algorithmic bytes = int8 input + int8 weights + fp32 output per launch; the 1x1 layers are bound by "
                              "the fp32 output stream, the 3x3 layers by the MFMA pipeline (see conv_i8.TOPs)", ops=conv_ops)
     else:
         main_roof = fq_roof
     if args.fused and conv["ms"] > fq["ms"] and args.model == "resnet50" and args.batch == 512:
-        main_roof["traffic"], src = pmc_traffic("conv_i8_dma_kernel")
+        main_roof["traffic"], src = pmc_traffic("conv_i8_mfma_kernel")
+        main_roof["traffic_measured_in_run"] = False
         if src:
             main_roof["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
     if args.fused:
@@ -290,13 +312,13 @@ def main():
         "metric": "ResNet-50 W8A8 fake-quant fwd images/sec" if args.model == "resnet50" else f"{args.model} W8A8 fake-quant fwd images/sec",
         "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
+        "scaling": args.scaling, "vs_baseline": None,
         # the arithmetic of the step: int8 x int8 -> int32 on the matrix cores with fp32 quantise / dequantise (int8 mode), or fp32
         "dtype": "i8" if args.int8 else "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} W8A8 per-channel fake-quant forward (FSPTQ forms: W minmax_channel s8, "
                                f"A minmax_tensor u8), {'BatchNorm kept' if args.keep_bn else 'BN folded first as in FSPTQuant.py:67'}, "
                                f"{'fused int8 MFMA conv/linear' if args.int8 else 'fp32 conv of the fake-quantised operands'}, "
-                               f"{'frozen execution plan (epilogue-fused ReLU / shortcut / next-layer codes), ' if args.fused else ''}"
+                               f"{'frozen execution plan (epilogue-fused ReLU / shortcut / next-layer codes; weight codes quantised once at plan build), ' if args.fused else ''}"
                                f"{str(args.streams) + ' HIP streams per GPU, ' if args.fused and args.streams > 1 else ''}"
                                f"224x224 {'relu(N(0,1))' if args.input == 'halfnormal' else 'N(0,1)'} pixels, batch {args.batch} per GPU, scales frozen",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},

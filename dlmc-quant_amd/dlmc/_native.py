@@ -41,6 +41,12 @@ SIGNATURES = {
     "dlmcq_rootq_weight_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
     "dlmcq_l2norm_scratch_bytes": (_sz, [_i64, _i64, _i64]),
     "dlmcq_l2norm_step_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _p, _sz, _p]),
+    "dlmcq_l2norm_iterate_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _p, _sz, _p]),
+    "dlmcq_l2out_scratch_bytes": (_sz, [_i64, _i64, _i64]),
+    "dlmcq_l2out_update_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _f32, _f32, _p, _sz, _p]),
+    "dlmcq_l2loss_scratch_bytes": (_sz, [_i64]),
+    "dlmcq_l2loss_tensor_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f32, _p, _sz, _p]),
+    "dlmcq_l2loss_rows_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _p]),
     "dlmcq_adaround_weight_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p]),
     "dlmcq_adaround_weight_bwd_f32": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p]),
     "dlmcq_quantize_weight_krsc_i8": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i32, _p]),

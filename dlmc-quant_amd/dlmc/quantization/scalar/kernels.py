@@ -240,6 +240,85 @@ def l2norm_step(x, scale, offset, lo, hi, ch_axis=None):
     return new.reshape(scale.shape)
 
 
+def l2norm_refine(x, scale, offset, lo, hi, ch_axis=None, eps=1e-5, batch=8):
+    """The whole l2norm refinement loop (ops.py:71-83 / :198-215) on the device: `batch` iterations per host check, each
+    of them a no-op once the convergence flag is set.  Returns the converged scale, shaped like `scale`."""
+    N.require_gpu(x)
+    x = x.detach().contiguous()
+    sc0 = _f32c(scale.detach(), x)
+    outer, ch, inner = geometry(x, sc0, ch_axis)
+    sc = sc0.reshape(-1).clone()
+    off = _f32c(offset, x)
+    if off is not None and off.numel() != sc.numel():
+        off = off.reshape(1).expand(sc.numel()).contiguous()
+    state = torch.zeros(3, dtype=torch.float32, device=x.device)
+    nb = N.lib.dlmcq_l2norm_scratch_bytes(outer, ch, inner)
+    scr = _scratch(nb, x.device)
+    while True:
+        N.check(N.lib.dlmcq_l2norm_iterate_f32(N.ptr(x), N.ptr(sc), N.ptr(off), N.ptr(state), outer, ch, inner, int(lo), int(hi),
+                                               int(batch), float(eps), N.ptr(scr), scr.numel() * 4, N.stream_ptr()))
+        if float(state[0]) != 0.0:          # one sync per `batch` iterations
+            break
+    return sc.reshape(scale.shape)
+
+
+class OutputAwareState:
+    """Device-side state of an output-aware refinement (l2norm_output / l2norm_output_channel)."""
+
+    def __init__(self, scale):
+        flat = scale.detach().to(torch.float32).reshape(-1)
+        self.scale = flat.clone()
+        self.best = torch.cat([flat, flat]).contiguous()           # [best | staging]
+        self.state = torch.tensor([0.0, 0.0, float("inf")], dtype=torch.float32, device=scale.device)
+
+    def done(self):
+        return float(self.state[0]) != 0.0
+
+    def iterations(self):
+        return int(self.state[1])
+
+
+def l2out_update(out, out_q, st, per_channel, eps=1e-5):
+    """One fused output-aware step on (out, out_q) [batch, channels, ...]: sums, new scale, best-scale bookkeeping and the
+    convergence flag, all on the device (dlmcq_l2out_update_f32)."""
+    N.require_gpu(out, out_q)
+    out, out_q = out.detach().contiguous(), out_q.detach().contiguous()
+    b, c = out.shape[0], out.shape[1]
+    inner = out.numel() // (b * c)
+    mse_div = float(out.numel() // c)                    # l2_loss: sum over axis 1, mean over the rest
+    nb = N.lib.dlmcq_l2out_scratch_bytes(b, c, inner)
+    scr = _scratch(nb, out.device)
+    N.check(N.lib.dlmcq_l2out_update_f32(N.ptr(out), N.ptr(out_q), N.ptr(st.scale), N.ptr(st.best), N.ptr(st.state), b, c, inner,
+                                         int(bool(per_channel)), mse_div, float(eps), N.ptr(scr), scr.numel() * 4, N.stream_ptr()))
+
+
+def l2loss_tensor(x, vmax, vmin, n_bits):
+    """quantize_l2loss_tensor's 80-candidate search in one read of x (dlmcq_l2loss_tensor_f32) -> (scale, zero point)."""
+    N.require_gpu(x)
+    x = x.detach().contiguous()
+    shape1 = x.shape[1] if x.dim() >= 2 else x.numel()
+    loss_div = float(x.numel() // shape1)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    offset = torch.empty(1, dtype=torch.float32, device=x.device)
+    nb = N.lib.dlmcq_l2loss_scratch_bytes(x.numel())
+    scr = _scratch(nb, x.device)
+    N.check(N.lib.dlmcq_l2loss_tensor_f32(N.ptr(x), N.ptr(_f32c(vmax, x).reshape(-1)), N.ptr(None if vmin is None else _f32c(vmin, x).reshape(-1)),
+                                          N.ptr(scale), N.ptr(offset), x.numel(), int(n_bits), loss_div, N.ptr(scr), scr.numel() * 4,
+                                          N.stream_ptr()))
+    return scale.reshape(()), offset.reshape(())
+
+
+def l2loss_rows(rows, scale, offset, n_bits):
+    """quantize_l2loss_channel's per-row search (dlmcq_l2loss_rows_f32).  rows [C, L]; scale / offset [C, 1] from the
+    min/max observer; returns the searched (scale, zero point), same shapes."""
+    N.require_gpu(rows)
+    rows = rows.detach().contiguous()
+    sc = _f32c(scale.detach(), rows).reshape(-1).clone()
+    off = _f32c(offset.detach(), rows).reshape(-1).clone()
+    N.check(N.lib.dlmcq_l2loss_rows_f32(N.ptr(rows), N.ptr(sc), N.ptr(off), rows.shape[0], rows.shape[1], int(n_bits), N.stream_ptr()))
+    return sc.reshape(scale.shape), off.reshape(offset.shape)
+
+
 def adaround_weight(w, alpha, scale, lo, hi, training):
     """Fused AdaRound weight forward; `scale` is the per-output-channel [K,1,..] scale."""
     N.require_gpu(w, alpha)

@@ -74,16 +74,12 @@ def quantize_minmax_pixel(tensor, n_bits, signed, allow_offset=True):
 
 # ------------------------------------------------------------------- iterative refinement
 def quantize_l2norm_tensor(tensor, n_bits, signed):
-    """ops.py:71-83."""
+    """ops.py:71-83: the whole loop runs on the device (csrc/estimator.hip: quantise + both reductions in one read per
+    iteration, convergence flag on device, one host check per 8 iterations)."""
     tensor = tensor.detach()
     scale, offset = quantize_minmax_tensor(tensor, n_bits, signed, allow_offset=True)
     lo, hi = get_qrange(signed, n_bits)
-    diff = float("inf")
-    while diff > 1e-5:
-        new_scale = K.l2norm_step(tensor, scale, offset, lo, hi)     # quantize + both reductions, one read
-        diff = float((new_scale - scale).abs() / scale)
-        scale = new_scale
-    return scale, offset
+    return K.l2norm_refine(tensor, scale, offset, lo, hi), offset
 
 
 def quantize_l2norm_channel(tensor, n_bits, signed, ch_axis=0):
@@ -92,108 +88,66 @@ def quantize_l2norm_channel(tensor, n_bits, signed, ch_axis=0):
     rows = rows.contiguous()
     scale, offset = quantize_minmax_channel(rows, n_bits, signed, ch_axis=0, allow_offset=True)
     lo, hi = get_qrange(signed, n_bits)
-    diff = float("inf")
-    while diff > 1e-5:
-        new_scale = K.l2norm_step(rows, scale, offset, lo, hi)       # per-row sums, one read
-        diff = float(((new_scale - scale) ** 2).sum().sqrt() / (scale ** 2).sum().sqrt())
-        scale = new_scale
+    scale = K.l2norm_refine(rows, scale, offset, lo, hi)
     return scale.reshape(new_shape), offset.reshape(new_shape)
+
+
+def _output_aware(input, weight, module, scale, offset, lo, hi, per_channel, patience):
+    """The loop shared by ops.py:85-109 and :252-292: per iteration one quantise kernel, the layer itself
+    (module._forward_func, as in the reference) and ONE fused kernel pair for the sums, the new scale, the best-scale
+    bookkeeping and the convergence flag; the host looks at the flag every 4 iterations."""
+    output = module._forward_func(input, weight)
+    st = K.OutputAwareState(scale)
+    count = 0
+    while count != patience:
+        for _ in range(min(4, patience - count)):
+            weight_q = quantize(weight, st.scale.reshape(scale.shape), offset, lo, hi)
+            K.l2out_update(output, module._forward_func(input, weight_q), st, per_channel)
+            count += 1
+        if st.done():
+            break
+    return st.best[:st.scale.numel()].reshape(scale.shape)
 
 
 def quantize_l2norm_output(input, weight, module, n_bits, signed, patience=1000):
     """ops.py:85-109: refine the weight scale against the layer OUTPUT."""
-    output = module._forward_func(input, weight)
     scale, offset = quantize_minmax_tensor(weight, n_bits, signed, allow_offset=True)
     lo, hi = get_qrange(signed, n_bits)
-    diff, best_mse, best_scale, count = float("inf"), float("inf"), scale, 0
-    while diff > 1e-5 and count != patience:
-        weight_q = quantize(weight, scale, offset, lo, hi)
-        output_q = module._forward_func(input, weight_q)
-        mse = l2_loss(output, output_q)
-        new_scale = (output_q * output).mean(axis=0).sum() / (output_q * output_q + 1e-7).mean(axis=0).sum()
-        diff = float((new_scale - scale).abs() / scale)
-        scale = new_scale
-        if mse < best_mse:
-            best_mse, best_scale = mse, scale
-        count += 1
-    return best_scale, offset
+    return _output_aware(input, weight, module, scale, offset, lo, hi, False, patience), offset
 
 
 def quantize_l2norm_output_channel(input, weight, module, n_bits, signed, ch_axis=0, patience=1000):
     """ops.py:252-292."""
     rows, new_shape = _rows(weight.detach(), ch_axis)
-    output = module._forward_func(input, weight)
-    batch, channel = output.shape[0], output.shape[1]
-    output = output.reshape(batch, channel, -1)
     scale, offset = quantize_minmax_channel(rows.contiguous(), n_bits, signed, ch_axis=0, allow_offset=True)
     scale, offset = scale.reshape(new_shape), offset.reshape(new_shape)
     lo, hi = get_qrange(signed, n_bits)
-    diff, best_mse, best_scale, count = float("inf"), float("inf"), scale, 0
-    while diff > 1e-5 and count != patience:
-        weight_q = quantize(weight, scale, offset, lo, hi)
-        output_q = module._forward_func(input, weight_q).reshape(batch, channel, -1)
-        new_scale = ((output * output_q).sum(axis=(0, 2)) / (output_q * output_q + 1e-7).sum(axis=(0, 2))).reshape(scale.shape)
-        mse = l2_loss(output, output_q)
-        diff = float(((new_scale - scale) ** 2).sum().sqrt() / (scale ** 2).sum().sqrt())
-        if mse < best_mse:
-            best_mse, best_scale = mse, scale
-        scale = new_scale
-        count += 1
-    return best_scale.reshape(new_shape), offset
+    return _output_aware(input, weight, module, scale, offset, lo, hi, True, patience).reshape(new_shape), offset
 
 
 # -------------------------------------------------------------------------- shrink search
-def _zp_fakequant(x, scale, zp, qmax):
-    """ops.py:58-60: (clamp(round(x/s) + zp, 0, qmax) - zp) * s  ==  the ZEROPOINT form minus the
-    round_pass identity; the search only compares losses, so it is evaluated with plain device ops."""
-    return ((torch.round(x / scale) + zp).clamp(0, qmax) - zp) * scale
-
-
 def quantize_l2loss_tensor(tensor, n_bits, signed, allow_offset=True):
-    """ops.py:36-68: 80-step shrink search with a rounded integer zero point (unsigned only)."""
+    """ops.py:36-68: 80-step shrink search with a rounded integer zero point (unsigned only): all 80 candidates are
+    evaluated in ONE read of the tensor (csrc/estimator.hip), the selection runs on the device."""
     tensor = tensor.detach()
     if signed:
         return quantize_minmax_tensor(tensor, n_bits, True)
     mx, mn = K.minmax(tensor)
     if not allow_offset:
         assert bool((mn >= 0).item())
-        mn = torch.zeros_like(mn)
-    qmax = 2 ** n_bits - 1
-    # all 80 candidates at once on device (the reference loops in Python with one sync per step)
-    shrink = 1 - 0.01 * torch.arange(80, device=tensor.device, dtype=torch.float32)
-    cand_scale = (shrink * mx - shrink * mn) / qmax
-    cand_zp = torch.round(-(shrink * mn) / cand_scale)
+        mn = None
     x2 = tensor if tensor.dim() >= 2 else tensor.reshape(1, -1)
-    losses = torch.stack([l2_loss(_zp_fakequant(x2, cand_scale[i], cand_zp[i], qmax), x2) for i in range(80)])
-    # first strict improvement over 1000 wins, then strictly better ones: = first argmin below 1000
-    best = int(torch.argmin(losses).item())
-    if not bool(losses[best] < 1000):
-        return mx / qmax, torch.zeros_like(mn)
-    return cand_scale[best], cand_zp[best]
+    return K.l2loss_tensor(x2, mx, mn, n_bits)
 
 
 def quantize_l2loss_channel(tensor, n_bits, signed, ch_axis=0):
-    """ops.py:169-196, including its aliasing quirk: `min_val` IS `offset`, so once a step is accepted
-    for a channel the following candidates shrink the accepted zero point, not the original minimum.
-    The C x 80 Python double loop becomes 80 vectorised steps over all channels."""
+    """ops.py:169-196, including its aliasing quirk (`min_val` IS `offset`, so once a step is accepted for a channel the
+    following candidates shrink the accepted zero point, not the original minimum): one workgroup per channel walks the
+    80 steps in order over its LDS-resident row (csrc/estimator.hip l2loss_rows_kernel)."""
     rows, new_shape = _rows(tensor.detach(), ch_axis)
     rows = rows.contiguous()
     scale, offset = quantize_minmax_channel(rows, n_bits, signed, ch_axis=0, allow_offset=True)
-    scale, offset = scale.clone(), offset.clone()       # [C,1]
-    qmax = 2 ** n_bits - 1
-    max_val = offset + scale * qmax
-    best = torch.full_like(scale, 1000.0)
-    for i in range(80):
-        new_min = (1 - 0.01 * i) * offset                 # `offset` doubles as min_val (the alias)
-        new_max = (1 - 0.01 * i) * max_val
-        new_scale = (new_max - new_min) / qmax
-        new_zp = torch.round(-new_min / new_scale)
-        tq = _zp_fakequant(rows, new_scale, new_zp, qmax)
-        loss = ((rows - tq) ** 2).sum(axis=1, keepdim=True)   # l2_loss of a single row = its squared error
-        take = best > loss
-        scale = torch.where(take, new_scale, scale)
-        offset = torch.where(take, new_zp, offset)
-        best = torch.where(take, loss, best)
+    scale, offset = K.l2loss_rows(rows, scale, offset, n_bits)
     return scale.reshape(new_shape), offset.reshape(new_shape)
 
 

@@ -237,6 +237,39 @@ int dlmcq_l2norm_step_f32(const float* x, const float* scale, const float* offse
                           int64_t outer, int64_t channels, int64_t inner, int32_t lo, int32_t hi,
                           void* scratch, size_t scratch_bytes, dlmcq_stream_t stream);
 
+/* The same refinement run to convergence WITHOUT host round trips: `iterations` iterations are enqueued; each one does
+ * nothing once state[0] != 0 (converged: |new - s| / s <= eps per tensor, ||new - s|| / ||s|| <= eps per channel,
+ * ops.py:77-81 / :205-210), so the caller reads the flag once per batch instead of syncing on `diff` every step.
+ * scale (in/out) [channels]; state = {done, iterations run, unused} (3 floats, zero-initialised by the caller). */
+int dlmcq_l2norm_iterate_f32(const float* x, float* scale, const float* offset, float* state, int64_t outer,
+                             int64_t channels, int64_t inner, int32_t lo, int32_t hi, int32_t iterations, float eps,
+                             void* scratch, size_t scratch_bytes, dlmcq_stream_t stream);
+
+/* One output-aware refinement step (ops.py:96-108 per tensor, :268-284 per output channel), fused: in ONE read of the
+ * layer output `out` and of `out_q` = the layer applied to the quantised weight ([outer, channels, inner] both),
+ *   s_new = SUM out*out_q / SUM (out_q*out_q + 1e-7),   mse = SUM (out - out_q)^2 / mse_div   (l2_loss, loss.py:22-24)
+ * then on device: the reference's best-scale bookkeeping (per tensor: scale <- s_new, best <- scale if mse improved;
+ * per channel: best <- OLD scale if mse improved, scale <- s_new) and the convergence flag as above.
+ * scale (in/out) [1 or channels]; best_scale [2 x that] (second half: staging); state = {done, iterations, best mse}. */
+size_t dlmcq_l2out_scratch_bytes(int64_t outer, int64_t channels, int64_t inner);
+int dlmcq_l2out_update_f32(const float* out, const float* out_q, float* scale, float* best_scale, float* state,
+                           int64_t outer, int64_t channels, int64_t inner, int32_t per_channel, float mse_div, float eps,
+                           void* scratch, size_t scratch_bytes, dlmcq_stream_t stream);
+
+/* quantize_l2loss_tensor (ops.py:36-68, unsigned): the 80-step shrink search in ONE read of x - 80 running squared errors
+ * per thread, candidates (scale_i, round(-min_i / scale_i)) derived on device from (vmax, vmin) - and the reference's
+ * selection (first loss below 1000, then strictly better ones).  loss_div = numel / shape[1] (l2_loss sums axis 1 and
+ * averages the rest).  vmin may be NULL (allow_offset = False).  scale / offset: one float each. */
+size_t dlmcq_l2loss_scratch_bytes(int64_t n);
+int dlmcq_l2loss_tensor_f32(const float* x, const float* vmax, const float* vmin, float* scale, float* offset, int64_t n,
+                            int32_t n_bits, float loss_div, void* scratch, size_t scratch_bytes, dlmcq_stream_t stream);
+
+/* quantize_l2loss_channel (ops.py:169-196) for [rows, inner] rows: one workgroup per row (cached in LDS up to 8192
+ * elements), the 80 steps in order with the reference's aliasing quirk (`min_val` is `offset`: an accepted step replaces
+ * the minimum by its zero point).  scale / offset [rows]: in = quantize_minmax_channel's result, out = the search's. */
+int dlmcq_l2loss_rows_f32(const float* x, float* scale, float* offset, int64_t rows, int64_t inner, int32_t n_bits,
+                          dlmcq_stream_t stream);
+
 /*
  * AdaRound weight path of the few-shot PTQ wrapper (FSPTQuant/base.py:69-79,136-141,151-152), per output channel:
  *   y = clamp(floor(w/s_k) + r, lo, hi) * s_k,  r = clamp(sigmoid(alpha)*1.2 - 0.1, 0, 1) when `training`, else [alpha >= 0]

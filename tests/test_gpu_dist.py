@@ -36,10 +36,15 @@ def _scales(net):
     return {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "scale" in k or "offset" in k}
 
 
-def _worker(rank, world, port, q, family):
+def _worker(rank, world, port, q, family, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":            # RCCL: one GPU per rank, the all-reduce runs on device buffers over xGMI
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     net, quantize_model, cfg = _net()
     cfg["momentum"] = 0.1
     quantize_model(net, cfg, None, quantization_type=family)
@@ -51,16 +56,14 @@ def _worker(rank, world, port, q, family):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-@pytest.mark.parametrize("family", ["FSPTQ", None, "RootQ"])
-def test_sharded_calibration_equals_single_process(family):
+def _run(family, backend):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, family)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, family, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -85,3 +88,19 @@ def test_sharded_calibration_equals_single_process(family):
             assert torch.equal(res[r][0][k], v), f"rank {r} {k}: {res[r][0][k]} vs {v}"
     got = torch.cat([res[0][1], res[1][1]])
     torch.testing.assert_close(got, full, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("family", ["FSPTQ", None, "RootQ"])
+def test_sharded_calibration_equals_single_process(family):
+    _run(family, "gloo")
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("family", ["FSPTQ", None, "RootQ"])
+def test_sharded_calibration_over_rccl(family):
+    """The same check with the observer all-reduce on RCCL (backend "nccl"), one GPU per rank, no host staging.  Needs two
+    GPUs: on a one-GPU box it is skipped - and says so - because two ranks cannot share a device under RCCL."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"RCCL needs one GPU per rank: this box has {torch.cuda.device_count()} (the gloo rehearsal above ran)")
+    _run(family, "nccl")
