@@ -1,0 +1,203 @@
+// Depthwise convolution on activation codes (groups = channels; modules/conv.py:13-19 with `groups`), the other half of a
+// MobileOne / MobileNet unit.  One multiply-add per output element and tap: nothing for the matrix cores to do, and the
+// layer is bound by HBM (1 byte read, 1 byte written per element), so this is plain vector arithmetic:
+//   * a thread owns 16 (3 x 3 kernels) or 4 consecutive channels of one output pixel; neighbouring threads own the
+//     neighbouring channel groups, so every tap is one coalesced row of C bytes and the 9 overlapping taps of neighbouring
+//     pixels are served by the vector cache;
+//   * the sums  S1 = SUM (q - zp) * qw  and  S0 = SUM (q - zp)  over the valid taps are small integers: they are kept in fp32
+//     EXACTLY (|S1| <= 9 * 255 * 255), so the arithmetic is the integer arithmetic of conv_i8.hip;
+//   * out = s_in * (s_w[c] * S1 + o_w[c] * S0) + bias[c]; asymmetric weights (w' = qw * s_w + o_w, ops.py:129-136) cost one
+//     more multiply-add per element; ReLU and the consumer's quantiser (conv_epilogue.h) follow in registers.
+#include "conv_epilogue.h"
+
+namespace dlmcq {
+
+struct DwGeom {
+  int N, H, W, C4, R, S, stride, pad, P, Q;    // C4 = C / 4
+  FastDiv cdiv, qdiv, pdiv;
+};
+
+__device__ __forceinline__ f32x4 bytes_u(uint32_t a) {
+  return f32x4{(float)(a & 0xff), (float)((a >> 8) & 0xff), (float)((a >> 16) & 0xff), (float)(a >> 24)};   // v_cvt_f32_ubyte0..3
+}
+__device__ __forceinline__ f32x4 bytes_s(uint32_t a) {
+  return f32x4{(float)(int8_t)a, (float)(int8_t)(a >> 8), (float)(int8_t)(a >> 16), (float)(int8_t)(a >> 24)};
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// 3 x 3, 16 channels per thread (C % 16 == 0): every tap is ONE 16-byte load per lane (the layer is bound by the number of
+// vector-memory instructions through the L1, not by arithmetic: 4-byte taps ran at 0.8 TB/s), all 9 taps and their weights
+// are requested before the first is used; a tap outside the image reads a clamped address and is replaced by the zero point.
+__global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ w,
+                                                                 float* __restrict__ out, const float* __restrict__ bias,
+                                                                 const float* __restrict__ s_in, const float* __restrict__ zp_in,
+                                                                 const float* __restrict__ s_w, const float* __restrict__ o_w,
+                                                                 DwGeom g, int x_signed, ConvEpi ep) {
+  const int C16 = g.C4 >> 2;
+  const int64_t total = (int64_t)g.N * g.P * g.Q * C16;
+  const float sin = s_in[0], zp = zp_in ? zp_in[0] : 0.0f;
+  const uint32_t zpw = (uint32_t)((int)zp & 0xff) * 0x01010101u;
+  const bool asym = o_w != nullptr;
+  const EpiQuant eq(ep);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t pix = fdiv((uint32_t)i, g.cdiv);                 // (cdiv divides by C / 16 here)
+    const int c16 = (int)((uint32_t)i - pix * (uint32_t)C16);
+    const uint32_t t = fdiv(pix, g.qdiv);
+    const int q = (int)(pix - t * (uint32_t)g.Q);
+    const uint32_t n = fdiv(t, g.pdiv);
+    const int p = (int)(t - n * (uint32_t)g.P);
+    const int h0 = p * g.stride - g.pad, w0 = q * g.stride - g.pad;
+    u32x4 a[9], b[9];
+    const u32x4* img = x + (int64_t)n * g.H * g.W * C16 + c16;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int h = h0 + r, ww = w0 + s;
+        const bool ok = h >= 0 && h < g.H && ww >= 0 && ww < g.W;
+        const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = ww < 0 ? 0 : (ww >= g.W ? g.W - 1 : ww);
+        const u32x4 v = img[((int64_t)hc * g.W + wc) * C16];
+        a[r * 3 + s] = ok ? v : u32x4{zpw, zpw, zpw, zpw};
+        b[r * 3 + s] = w[(r * 3 + s) * C16 + c16];
+      }
+    const int c = c16 * 16;
+    uint32_t codes[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {                                   // 4 channels at a time
+      f32x4 s1 = {0.0f, 0.0f, 0.0f, 0.0f}, s0 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        f32x4 av = x_signed ? bytes_s(a[k][d]) : bytes_u(a[k][d]);
+        const f32x4 bv = bytes_s(b[k][d]);
+        if (zp != 0.0f) av = f32x4{av.x - zp, av.y - zp, av.z - zp, av.w - zp};
+        s1 = f32x4{__builtin_fmaf(av.x, bv.x, s1.x), __builtin_fmaf(av.y, bv.y, s1.y), __builtin_fmaf(av.z, bv.z, s1.z),
+                   __builtin_fmaf(av.w, bv.w, s1.w)};      // exact: integers far below 2^24
+        if (asym) s0 = f32x4{s0.x + av.x, s0.y + av.y, s0.z + av.z, s0.w + av.w};
+      }
+      const int cc = c + d * 4;
+      const f32x4 sw = *reinterpret_cast<const f32x4*>(s_w + cc);
+      f32x4 v = f32x4{s1.x * (sin * sw.x), s1.y * (sin * sw.y), s1.z * (sin * sw.z), s1.w * (sin * sw.w)};
+      if (asym) {
+        const f32x4 ow = *reinterpret_cast<const f32x4*>(o_w + cc);
+        v = f32x4{v.x + s0.x * (sin * ow.x), v.y + s0.y * (sin * ow.y), v.z + s0.z * (sin * ow.z), v.w + s0.w * (sin * ow.w)};
+      }
+      if (bias) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + cc);
+        v = f32x4{v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w};
+      }
+      if (ep.relu) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
+      const int64_t at = (int64_t)pix * g.C4 * 4 + cc;
+      if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
+      if (ep.codes) codes[d] = eq.code4(v);
+    }
+    if (ep.codes) __builtin_nontemporal_store(u32x4{codes[0], codes[1], codes[2], codes[3]},
+                                              reinterpret_cast<u32x4*>(ep.codes + (int64_t)pix * g.C4 * 4 + c));
+  }
+}
+
+// Any R, S <= 7 and C % 4 == 0: one dword of codes per thread and tap.
+__global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw_i8_kernel(const uint32_t* __restrict__ x, const uint32_t* __restrict__ w,
+                                                                float* __restrict__ out, const float* __restrict__ bias,
+                                                                const float* __restrict__ s_in, const float* __restrict__ zp_in,
+                                                                const float* __restrict__ s_w, const float* __restrict__ o_w,
+                                                                DwGeom g, int x_signed, ConvEpi ep) {
+  const int64_t total = (int64_t)g.N * g.P * g.Q * g.C4;
+  const float sin = s_in[0], zp = zp_in ? zp_in[0] : 0.0f;
+  const EpiQuant eq(ep);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t pix = fdiv((uint32_t)i, g.cdiv);
+    const int c4 = (int)((uint32_t)i - pix * (uint32_t)g.C4);
+    const uint32_t t = fdiv(pix, g.qdiv);
+    const int q = (int)(pix - t * (uint32_t)g.Q);
+    const uint32_t n = fdiv(t, g.pdiv);
+    const int p = (int)(t - n * (uint32_t)g.P);
+    const int h0 = p * g.stride - g.pad, w0 = q * g.stride - g.pad;
+    f32x4 s1 = {0.0f, 0.0f, 0.0f, 0.0f}, s0 = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int r = 0; r < g.R; ++r) {
+      const int h = h0 + r;
+      if (h < 0 || h >= g.H) continue;
+      for (int s = 0; s < g.S; ++s) {
+        const int ww = w0 + s;
+        if (ww < 0 || ww >= g.W) continue;                       // padded tap: x' = 0
+        const uint32_t a = x[(((int64_t)n * g.H + h) * g.W + ww) * g.C4 + c4];
+        f32x4 av = x_signed ? bytes_s(a) : bytes_u(a);
+        const f32x4 bv = bytes_s(w[(r * g.S + s) * g.C4 + c4]);
+        av = f32x4{av.x - zp, av.y - zp, av.z - zp, av.w - zp};
+        s1 = f32x4{__builtin_fmaf(av.x, bv.x, s1.x), __builtin_fmaf(av.y, bv.y, s1.y), __builtin_fmaf(av.z, bv.z, s1.z),
+                   __builtin_fmaf(av.w, bv.w, s1.w)};
+        s0 = f32x4{s0.x + av.x, s0.y + av.y, s0.z + av.z, s0.w + av.w};
+      }
+    }
+    const int c = c4 * 4;
+    const f32x4 sw = *reinterpret_cast<const f32x4*>(s_w + c);
+    f32x4 v = f32x4{s1.x * (sin * sw.x), s1.y * (sin * sw.y), s1.z * (sin * sw.z), s1.w * (sin * sw.w)};
+    if (o_w) {
+      const f32x4 ow = *reinterpret_cast<const f32x4*>(o_w + c);
+      v = f32x4{v.x + s0.x * (sin * ow.x), v.y + s0.y * (sin * ow.y), v.z + s0.z * (sin * ow.z), v.w + s0.w * (sin * ow.w)};
+    }
+    if (bias) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + c);
+      v = f32x4{v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w};
+    }
+    if (ep.relu) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
+    const int64_t at = (int64_t)pix * g.C4 * 4 + c;
+    if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
+    if (ep.codes) __builtin_nontemporal_store(eq.code4(v), reinterpret_cast<uint32_t*>(ep.codes + at));
+  }
+}
+
+}  // namespace dlmcq
+
+using namespace dlmcq;
+
+extern "C" int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* out, const float* bias, const float* in_scale,
+                                       const float* in_zero_point, const float* w_scale, const float* w_offset, int64_t N,
+                                       int64_t H, int64_t W, int64_t C, int64_t R, int64_t S, int32_t stride, int32_t pad,
+                                       int32_t x_is_unsigned, int32_t relu, void* codes, const float* q_scale,
+                                       const float* q_zero_point, int32_t q_lo, int32_t q_hi, int32_t q_form, float q_ste_g,
+                                       dlmcq_stream_t stream) {
+  if (N < 0 || H < 1 || W < 1 || C < 4 || (C & 3) || R < 1 || S < 1 || R > 7 || S > 7 || stride < 1 || pad < 0) return DLMCQ_EINVAL;
+  const int64_t P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+  if (P < 1 || Q < 1) return DLMCQ_EINVAL;
+  if (N == 0) return DLMCQ_OK;
+  if (!x || !w || !(out || codes) || !in_scale || !w_scale) return DLMCQ_EINVAL;
+  if (codes && (!q_scale || q_lo > q_hi || q_lo < -128 || q_hi > 255 || q_hi - q_lo > 255 || q_form < DLMCQ_FORM_EMULATE ||
+                q_form > DLMCQ_FORM_SYMMETRIC))
+    return DLMCQ_EINVAL;
+  if (!aligned4(x) || !aligned4(w) || !aligned16(w_scale) || (w_offset && !aligned16(w_offset)) || (bias && !aligned16(bias)) ||
+      (out && !aligned16(out)) || (codes && !aligned4(codes)))
+    return DLMCQ_EALIGN;
+  if (N * P * Q * (C / 4) >= (1ll << 31) || N * H * W * (C / 4) >= (1ll << 31)) return DLMCQ_ERANGE;
+  DwGeom g;
+  g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C4 = (int)(C / 4); g.R = (int)R; g.S = (int)S; g.stride = stride; g.pad = pad;
+  g.P = (int)P; g.Q = (int)Q;
+  g.cdiv = make_fastdiv((uint32_t)g.C4);
+  g.qdiv = make_fastdiv((uint32_t)Q);
+  g.pdiv = make_fastdiv((uint32_t)P);
+  ConvEpi ep{};
+  ep.relu = relu != 0;
+  ep.codes = static_cast<uint8_t*>(codes);
+  ep.q_scale = q_scale;
+  ep.q_zp = q_zero_point;
+  ep.q_lo = (float)q_lo;
+  ep.q_hi = (float)q_hi;
+  ep.q_g = q_ste_g;
+  ep.q_form = q_form;
+  const int64_t total = N * P * Q * (C / 4);
+  const int64_t blocks = (total + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool wide = R == 3 && S == 3 && C % 16 == 0 && aligned16(x) && aligned16(w) && (!codes || aligned16(codes));
+  if (wide) {
+    g.cdiv = make_fastdiv((uint32_t)(C / 16));
+    const int64_t b16 = (N * P * Q * (C / 16) + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
+    hipLaunchKernelGGL(conv_dw3_i8_kernel, dim3((uint32_t)(b16 < (1 << 20) ? b16 : (1 << 20))), dim3(DLMCQ_BLOCK), 0, st,
+                       static_cast<const u32x4*>(x), reinterpret_cast<const u32x4*>(w), out, bias, in_scale, in_zero_point, w_scale,
+                       w_offset, g, x_is_unsigned ? 0 : 1, ep);
+  } else {
+    hipLaunchKernelGGL(conv_dw_i8_kernel, dim3((uint32_t)(blocks < (1 << 20) ? blocks : (1 << 20))), dim3(DLMCQ_BLOCK), 0, st,
+                       static_cast<const uint32_t*>(x), reinterpret_cast<const uint32_t*>(w), out, bias, in_scale, in_zero_point, w_scale,
+                       w_offset, g, x_is_unsigned ? 0 : 1, ep);
+  }
+  return launch_status();
+}

@@ -14,6 +14,8 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 // tensor, the ReLU pass and the consumer's quantise pass never touch HBM.  Same arithmetic, same order, as the
 // separate kernels (fq_one), hence bit-identical codes.
 struct ConvEpi {
+  const float* w_off;      // asymmetric per-channel weights w' = qw * s_w[k] + w_off[k] (ops.py:129-136): the extra term
+                           // w_off[k] * SUM x' of the convolution, from a per-pixel sum of the activation codes (conv_i8.hip)
   const float* residual;
   uint8_t* codes;
   const float* q_scale;

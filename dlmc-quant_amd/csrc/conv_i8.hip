@@ -41,8 +41,8 @@ namespace dlmcq {
 //   * everything the epilogue needs from memory (per-channel scale / code sum / bias of both pairs and, for 64-wide
 //     tiles, the fp32 shortcut tile) is requested BEFORE the first operand, so that a tile pays one memory round trip,
 //     not four in a row: at ResNet sizes most tiles have 1-8 K steps and their lifetime is latency, not work.
-template <int BN, bool DUAL, bool ADIR>
-__global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 64 ? 4 : 3))) void conv_i8_mfma_kernel(
+template <int BN, bool DUAL, bool ADIR, bool ASYM = false>
+__global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ bias,
     const int32_t* __restrict__ wsum, const float* __restrict__ s_in, const float* __restrict__ zp_in,
     const float* __restrict__ s_w, ConvGeom g, int shift, ConvEpi ep, ConvSeg2 sg) {
@@ -59,8 +59,10 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 6
   constexpr int NH = NT / 2 + (NT & 1); // epilogue passes of 64 channels
   constexpr bool EARLY_RES = NH == 1;   // the whole shortcut tile is one pass: request it before the operands
   constexpr int GROUP = (ADIR ? KS : AI) + BI;   // vector-memory instructions per K step per wave
-  constexpr int NPAR = DUAL ? 6 : 3;    // per-channel constant arrays of the epilogue: (scale, code sum, bias) per pair
-  __shared__ __attribute__((aligned(1024))) int8_t lds[LDS_BYTES + NPAR * BN * 4];
+  constexpr int NPAR = DUAL ? 6 : (ASYM ? 4 : 3);   // per-channel constant arrays of the epilogue: (scale, code sum, bias) per pair (+ weight offset)
+  constexpr int PAR_BYTES = NPAR * BN * 4;
+  static_assert(!(ASYM && DUAL), "asymmetric weights: single pair only");
+  __shared__ __attribute__((aligned(1024))) int8_t lds[LDS_BYTES + PAR_BYTES + (ASYM ? 4 * 32 * 4 : 0)];
 
   // XCD-aware tile order: the workgroups that share an activation tile (same row block, different column blocks) are
   // consecutive in `tile`, and consecutive tiles are dealt to the SAME XCD (its L2 then serves the re-reads)
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 6
   request_par(std::integral_constant<int, 0>{}, s_w);
   request_par(std::integral_constant<int, 1>{}, wsum);
   request_par(std::integral_constant<int, 2>{}, bias);
+  if (ASYM) request_par(std::integral_constant<int, 3>{}, ep.w_off);
   if (DUAL) {
     request_par(std::integral_constant<int, 3>{}, sg.s_w);
     request_par(std::integral_constant<int, 4>{}, sg.wsum);
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 6
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0;
   float extra[DUAL ? NT : 1][16];
+  int s0 = 0;        // ASYM: running sum of this lane's share of its row's operand bytes (all taps, all channels)
 
   static_for<PF>([&](auto i) {
     if (decltype(i)::value < nsteps) issue_next(i);
@@ -272,6 +276,12 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 6
         t = *reinterpret_cast<const i32x4*>(base + arow * BK + ((sg_ ^ ((arow >> 2) & 3)) << 4));
       }
       const i32x4 af = i32x4{(int)(t.x ^ xorw), (int)(t.y ^ xorw), (int)(t.z ^ xorw), (int)(t.w ^ xorw)};
+      if (ASYM) {    // SUM of the int8 operand over the reduction (v_dot4_i32_i8 with a vector of ones)
+        s0 = __builtin_amdgcn_sdot4(af.x, 0x01010101, s0, false);
+        s0 = __builtin_amdgcn_sdot4(af.y, 0x01010101, s0, false);
+        s0 = __builtin_amdgcn_sdot4(af.z, 0x01010101, s0, false);
+        s0 = __builtin_amdgcn_sdot4(af.w, 0x01010101, s0, false);
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int brow = j * 32 + l31;
@@ -288,13 +298,26 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 6
   // ---- epilogue: one rounding chain  v = (acc + (shift - zp) * SUM qw) * (s_in * s_w[k]) + b[k] ----
   const float sin = s_in[0];
   const EpiQuant eq(ep);
-  float mult[NT], p_bias[NT];
+  float mult[NT], p_bias[NT], woff[ASYM ? NT : 1];
   int corr[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     mult[j] = sin * par_f(0, j);
     corr[j] = (shift - zpi) * par_i(1, j);
     p_bias[j] = bias ? par_f(2, j) : 0.0f;
+    if (ASYM) woff[ASYM ? j : 0] = sin * par_f(3, j);
+  }
+  // ASYM: SUM x' of a row = s_in * (SUM q' + (shift - zp) * taps * channels); lanes r and r + 32 hold the two halves of row r.
+  // The sums go through a small LDS table into the accumulator layout (register i = row (i & 3) + 8 (i >> 2) + 4 hsel).
+  float s0r[ASYM ? 16 : 1];
+  if (ASYM) {
+    s0 += __shfl_xor(s0, 32, 64);
+    s0 += (shift - zpi) * (g.R * g.S * g.C);
+    int* tab = reinterpret_cast<int*>(lds + LDS_BYTES + PAR_BYTES) + wave * 32;
+    if (hsel == 0) tab[l31] = s0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (a wave reads only its own 32 sums)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s0r[ASYM ? i : 0] = (float)tab[(i & 3) + 8 * (i >> 2) + 4 * hsel];
   }
   if ((g.K & 3) == 0) {
     // through LDS: accumulator layout (lane = channel, register = row) -> row-major, so that each lane stores 16 B and
@@ -314,6 +337,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 6
           const int r = (i & 3) + 8 * (i >> 2) + 4 * hsel;
           float v = (float)(acc[j][i] + corr[j]) * mult[j] + p_bias[j];
           if (DUAL) v = v + extra[DUAL ? j : 0][i];
+          if (ASYM) v = v + s0r[ASYM ? i : 0] * woff[ASYM ? j : 0];
           stg[r * EP_LD + jj * 32 + l31] = v;
         }
       });
@@ -349,6 +373,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 6
       const int64_t at = row * g.K + col;
       float v = (float)(acc[j][i] + corr[j]) * mult[j] + p_bias[j];
       if (DUAL) v = v + extra[DUAL ? j : 0][i];
+      if (ASYM) v = v + s0r[ASYM ? i : 0] * woff[ASYM ? j : 0];
       if (ep.residual) v = v + ep.residual[at];
       if (ep.relu) v = relu_nan(v);
       if (out) __builtin_nontemporal_store(v, out + at);
@@ -464,12 +489,15 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
     s2 = *seg2;
     s2.g.nblk_m = g.nblk_m;
     s2.g.nblk_n = g.nblk_n;
-    if (s2.g.M != g.M || s2.g.K != g.K || s2.g.P != g.P || s2.g.Q != g.Q) return DLMCQ_EINVAL;
+    if (s2.g.M != g.M || s2.g.K != g.K || s2.g.P != g.P || s2.g.Q != g.Q || ep.w_off) return DLMCQ_EINVAL;
   }
 #define DLMCQ_CONV_ARGS dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, s2
   if (seg2) {
     if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, true, true>), DLMCQ_CONV_ARGS);
     else hipLaunchKernelGGL((conv_i8_mfma_kernel<128, true, true>), DLMCQ_CONV_ARGS);
+  } else if (ep.w_off) {     // asymmetric per-channel weights (activations direct: the row sums come from their fragments)
+    if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, true, true>), DLMCQ_CONV_ARGS);
+    else hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, true>), DLMCQ_CONV_ARGS);
   } else if (!plan.adir) {
     if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, false>), DLMCQ_CONV_ARGS);
     else hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, false>), DLMCQ_CONV_ARGS);
@@ -513,6 +541,20 @@ extern "C" int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float*
                                           const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
                                           int32_t q_form, float q_ste_g, dlmcq_stream_t stream) {
   const ConvEpi ep = make_epi(residual, relu, codes, q_scale, q_zero_point, q_lo, q_hi, q_form, q_ste_g);
+  return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
+                     x_is_unsigned, stream, ep);
+}
+
+extern "C" int dlmcq_conv2d_i8_nhwc_asym(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                                         const float* in_scale, const float* in_zero_point, const float* w_scale,
+                                         const float* w_offset, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R,
+                                         int64_t S, int32_t stride, int32_t pad, int32_t dilation, int32_t x_is_unsigned,
+                                         const float* residual, int32_t relu, void* codes, const float* q_scale,
+                                         const float* q_zero_point, int32_t q_lo, int32_t q_hi, int32_t q_form, float q_ste_g,
+                                         dlmcq_stream_t stream) {
+  if (!w_offset) return DLMCQ_EINVAL;
+  ConvEpi ep = make_epi(residual, relu, codes, q_scale, q_zero_point, q_lo, q_hi, q_form, q_ste_g);
+  ep.w_off = w_offset;
   return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
                      x_is_unsigned, stream, ep);
 }

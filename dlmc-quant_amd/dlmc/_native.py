@@ -54,6 +54,10 @@ SIGNATURES = {
                                                _i32, _i32, _i32, _i32, _p]),
     "dlmcq_conv2d_i8_nhwc_fused": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                                  _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
+    "dlmcq_conv2d_i8_nhwc_asym": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                                _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
+    "dlmcq_conv2d_dw_i8_nhwc": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32,
+                                              _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
     "dlmcq_conv2d_i8_nhwc_dual": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                                 _i32, _i32, _i32, _i32,
                                                 _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32,

@@ -373,14 +373,15 @@ class EmitCodes:
 
 
 def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1,
-              residual=None, relu=False, emit=None, want_out=True):
+              residual=None, relu=False, emit=None, want_out=True, w_offset=None):
     """Fused int8 conv / linear on the matrix cores.  `codes`: uint8/int8 activation codes, logically
     (N, C, H, W) in channels_last memory, or (N, C) for a linear layer.  Returns fp32 (N, K, P, Q) in
     channels_last memory (or (N, K)).
 
     Epilogue options (dlmcq_conv2d_i8_nhwc_fused): `residual` (fp32, the output's shape and layout) is added,
     `relu` applied, and with `emit=EmitCodes(...)` the consumer's activation codes of the result are written as
-    well; the return value is then `(out, out_codes)`, `out` being None when `want_out=False`."""
+    well; the return value is then `(out, out_codes)`, `out` being None when `want_out=False`.
+    `w_offset` ([K] fp32): asymmetric per-channel weights w' = qw * s_w[k] + w_offset[k] (dlmcq_conv2d_i8_nhwc_asym)."""
     N.require_gpu(codes, wq)
     linear = codes.dim() == 2
     if linear:
@@ -399,9 +400,11 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
         if linear:
             return torch.empty((n, K), dtype=dtype, device=codes.device)
         return torch.empty((n, K, P, Q), dtype=dtype, device=codes.device, memory_format=torch.channels_last)
-    fused = residual is not None or relu or emit is not None
+    fused = residual is not None or relu or emit is not None or w_offset is not None
     if not want_out and emit is None:
         raise ValueError("conv2d_i8: nothing to produce (want_out=False without emit)")
+    if w_offset is not None:
+        w_offset = _f32c(w_offset.detach(), codes).reshape(-1)
     out = alloc(torch.float32) if want_out else None
     ref = codes   # device / dtype anchor for the small parameter tensors
     w_scale = _f32c(w_scale.detach(), ref).reshape(-1)
@@ -431,13 +434,56 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
             q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, ref).reshape(-1)
             lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
         nbytes = codes.numel() + wq.numel() + out_elems * (4 * (out is not None) + 4 * (residual is not None) + (emit is not None))
-        PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_fused(
-            *args, N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g,
-            N.stream_ptr())))
+        if w_offset is not None:
+            PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_asym(
+                *args[:8], N.ptr(w_offset), *args[8:], N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp),
+                lo, hi, form, g, N.stream_ptr())))
+        else:
+            PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_fused(
+                *args, N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g,
+                N.stream_ptr())))
         return (out, out_codes) if emit is not None else out
     args = args + (N.stream_ptr(),)
     PROFILE.launch("conv_i8", codes.numel() + out_elems * 4 + wq.numel(), lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(*args)))
     return out
+
+
+def conv2d_dw_i8(codes, wq, bias, in_scale, in_zp, w_scale, w_offset=None, stride=1, padding=0, relu=False, emit=None, want_out=True):
+    """Depthwise convolution on activation codes (dlmcq_conv2d_dw_i8_nhwc).  codes: (N, C, H, W) uint8/int8 channels_last,
+    C % 4 == 0; wq: int8 [R, S, C] (tap-major); per-channel w_scale / w_offset / bias [C].  Returns fp32 (N, C, P, Q)
+    channels_last, or `(out, codes)` with `emit`."""
+    N.require_gpu(codes, wq)
+    n, c, h, w_ = codes.shape
+    if not codes.is_contiguous(memory_format=torch.channels_last):
+        codes = codes.contiguous(memory_format=torch.channels_last)
+    R, S, _ = wq.shape
+    P, Q = (h + 2 * padding - R) // stride + 1, (w_ + 2 * padding - S) // stride + 1
+    if not want_out and emit is None:
+        raise ValueError("conv2d_dw_i8: nothing to produce (want_out=False without emit)")
+
+    def alloc(dtype):
+        return torch.empty((n, c, P, Q), dtype=dtype, device=codes.device, memory_format=torch.channels_last)
+    out = alloc(torch.float32) if want_out else None
+    w_scale = _f32c(w_scale.detach(), codes).reshape(-1)
+    w_offset = None if w_offset is None else _f32c(w_offset.detach(), codes).reshape(-1)
+    in_scale = _f32c(in_scale.detach(), codes).reshape(-1)
+    in_zp = None if in_zp is None else _f32c(in_zp, codes).reshape(-1)
+    bias = None if bias is None else bias.detach().contiguous()
+    out_codes = q_scale = q_zp = None
+    lo = hi = form = 0
+    g = 0.0
+    if emit is not None:
+        out_codes = alloc(emit.dtype)
+        q_scale = _f32c(emit.scale.detach(), codes).reshape(-1)
+        q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, codes).reshape(-1)
+        lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
+    oe = n * c * P * Q
+    PROFILE.launch("conv_dw", codes.numel() + wq.numel() + oe * (4 * want_out + (emit is not None)),
+                   lambda: N.check(N.lib.dlmcq_conv2d_dw_i8_nhwc(
+                       N.ptr(codes), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale), N.ptr(w_offset),
+                       n, h, w_, c, R, S, int(stride), int(padding), int(codes.dtype == torch.uint8), int(bool(relu)), N.ptr(out_codes),
+                       N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())))
+    return (out, out_codes) if emit is not None else out
 
 
 def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True):

@@ -55,18 +55,51 @@ def _byte_range(lo, hi):
     return (0 <= lo and hi <= 255) or (-128 <= lo and hi <= 127)
 
 
-def _frozen_spec(mod):
-    """(_ActSpec, weight scale, weight lo, weight hi, kind) if `mod` can run on an int8 kernel with frozen scales;
-    kind "gemm" = conv_i8.hip (input channels % 64 == 0), "stem" = conv_stem_i8.hip (<= 4 input channels)."""
-    spec = _frozen_spec_(mod)
-    return None if spec is None else spec + (int8_kind(mod),)
+def _ceil64(n):
+    return (n + 63) // 64 * 64
 
 
-def _frozen_spec_(mod):
-    if int8_kind(mod) is None:
+def plan_kind(mod):
+    """Which kernel of the frozen plan runs `mod`: "gemm" = conv_i8.hip (dense conv / linear; channel counts that are no
+    multiple of 64 are zero-padded when the plan is built), "stem" = conv_stem_i8.hip (<= 4 input channels), "dw" =
+    conv_dw_i8.hip (depthwise), or None."""
+    k = int8_kind(mod)
+    if k is not None:
+        return k
+    w = mod.weight
+    sq = lambda t: len(set(t)) == 1  # noqa: E731
+    if w.dim() != 4 or mod.padding_mode != "zeros" or isinstance(mod.padding, str) or not (sq(mod.stride) and sq(mod.padding)):
         return None
+    if tuple(mod.dilation) != (1, 1):
+        return None
+    if mod.groups == 1 and w.shape[1] % 4 == 0 and w.shape[1] > 4:
+        return "gemm"
+    if mod.groups == w.shape[0] and w.shape[1] == 1 and w.shape[0] % 4 == 0 and w.shape[2] <= 7 and w.shape[3] <= 7:
+        return "dw"
+    return None
+
+
+def _frozen_spec(mod):
+    """(_ActSpec, weight scale, weight lo, weight hi, kind, weight offset, weight-code function) if `mod` can run on an
+    int8 kernel with frozen scales.  The last two are None for symmetric per-tensor / per-channel weights quantised by
+    quantize_weight_krsc; asymmetric (offset = channel minimum, ops.py:129-136) or QBase per-channel weights carry their
+    float offsets [K] and a function returning the module's own integer codes [K, C, R, S]."""
+    kind = plan_kind(mod)
+    if kind is None:
+        return None
+    spec = _frozen_spec_(mod, kind)
+    if spec is None:
+        return None
+    if len(spec) == 4:
+        spec = spec + (None, None)
+    if kind == "stem" and spec[4] is not None:
+        return None                       # (the first-layer kernel has no weight-offset term)
+    return spec[:4] + (kind,) + spec[4:]
+
+
+def _frozen_spec_(mod, kind):
     if isinstance(mod, FSPTQBase):
-        if not (mod.act_quant and mod.wt_quant) or mod.in_scale.numel() != 1:
+        if kind == "dw" or not (mod.act_quant and mod.wt_quant) or mod.in_scale.numel() != 1:
             return None
         if mod.qconfig["weight"].get("recon_type") in ("adaround", "dist_recon"):
             return None
@@ -85,18 +118,31 @@ def _frozen_spec_(mod):
         cfg = mod.qconfig
         if not (cfg["input"]["enable"] and cfg["weight"]["enable"]):
             return None
-        if mod.in_scale.numel() != 1 or mod.wt_scale.numel() != 1:
+        k = mod.weight.shape[0]
+        per_channel = mod.wt_scale.numel() != 1
+        if mod.in_scale.numel() != 1 or (per_channel and (mod.wt_scale.numel() != k or mod.wt_scale.shape[0] != k)):
             return None
         if not (mod._init.ready(mod, "in_init_state") and mod._init.ready(mod, "wt_init_state")):
             raise RuntimeError("fuse_inference: run a calibration forward first (scales are not initialised)")
-        if not (_byte_range(mod.in_min_val, mod.in_max_val) and -128 <= mod.wt_min_val and mod.wt_max_val <= 127):
+        lo, hi = mod.wt_min_val, mod.wt_max_val
+        if not (_byte_range(mod.in_min_val, mod.in_max_val) and _byte_range(lo, hi)):
             return None
-        if float(mod.in_offset.abs().max()) != 0 or float(mod.wt_offset.abs().max()) != 0:
-            return None
+        if float(mod.in_offset.abs().max()) != 0:
+            return None                  # a float activation offset has no integer zero point (padding must be a code)
+        asym = mod.wt_offset is not None and float(mod.wt_offset.abs().max()) != 0
         act = _ActSpec(mod.in_scale.detach().reshape(-1)[:1].clone(), None, mod.in_min_val, mod.in_max_val,
                        N.FORM_QBASE, True)
-        g_w = 1 / math.sqrt(mod.weight.numel() * mod.wt_max_val)
-        return act, ste_scale_value(mod.wt_scale, g_w).clone(), mod.wt_min_val, mod.wt_max_val
+        g_w = 1 / math.sqrt(mod.weight.numel() * hi)
+        s_hat = ste_scale_value(mod.wt_scale, g_w).clone()
+        if not (per_channel or asym or hi > 127 or kind == "dw"):
+            return act, s_hat, lo, hi
+        w_off = mod.wt_offset.detach().to(torch.float32).reshape(-1).clone() if asym else None
+
+        def codes(mod=mod, g_w=g_w, lo=lo, hi=hi):      # the module's own weight quantiser (form QBASE), as integers
+            off = mod.wt_offset if mod.wt_offset is not None else None
+            return K.fake_quant(mod.weight.detach(), mod.wt_scale.detach(), off, lo, hi, N.FORM_QBASE, g=g_w, codes="i8",
+                                want_y=False)[1]
+        return act, s_hat, lo, hi, w_off, codes
     return None
 
 
@@ -107,13 +153,30 @@ class _PlanLayer(nn.Module):
     def __init__(self, layer, spec, relu=False, emit=None, want_out=True, pool=None):
         super().__init__()
         self.layer = layer
-        self.act, w_scale, self.w_lo, self.w_hi, self.kind = spec
+        self.act, w_scale, self.w_lo, self.w_hi, self.kind, w_off, self._w_codes = spec
         self.relu, self.emit, self.want_out, self.pool = bool(relu), emit, bool(want_out), pool
         k = layer.weight.shape[0]
+        # channel counts that are no multiple of 64 (the K step of the matrix-core kernel) are zero-padded: padded output
+        # channels have zero weights and bias, so their value is 0 and their code is the consumer's code of 0
+        self.k, self.k_pad = k, (_ceil64(k) if self.kind in ("gemm", "dw") and layer.weight.dim() == 4 else k)
         w_scale = w_scale.detach().to(torch.float32).reshape(-1)
-        self.register_buffer("w_scale", (w_scale.expand(k) if w_scale.numel() == 1 else w_scale).contiguous(),
+        w_scale = w_scale.expand(k) if w_scale.numel() == 1 else w_scale
+        self.register_buffer("w_scale", self._padk(w_scale, 1.0), persistent=False)
+        if w_off is not None:
+            w_off = w_off.expand(k) if w_off.numel() == 1 else w_off
+        self.register_buffer("w_off", None if w_off is None else self._padk(w_off.to(w_scale.device), 0.0), persistent=False)
+        self.register_buffer("bias_pad", None if layer.bias is None or self.k_pad == k else self._padk(layer.bias.detach().float(), 0.0),
                              persistent=False)
         self._deq = {}     # QBase dequantises with s^ = grad_scale(s, g(numel)): one tiny tensor per input size
+
+    def _padk(self, v, fill):
+        v = v.detach().reshape(-1)
+        if self.k_pad == v.numel():
+            return v.contiguous()
+        return torch.cat([v, torch.full((self.k_pad - v.numel(),), fill, dtype=v.dtype, device=v.device)]).contiguous()
+
+    def _bias(self):
+        return self.layer.bias if self.bias_pad is None else self.bias_pad
 
     def _in_scale(self, numel):
         if not self.act.needs_g:
@@ -135,7 +198,33 @@ class _PlanLayer(nn.Module):
     def _finish(self, out, codes):
         if self.pool is not None:
             codes = K.maxpool_codes(codes, *self.pool)
+        if out is not None and self.k_pad != self.k:
+            out = out[:, :self.k]          # fp32 leaves the plan: drop the padding channels (codes stay padded for plan consumers)
         return out, codes
+
+
+def _pad_channels(codes, c_pad, fill):
+    """Activation codes (N, C, H, W) channels_last -> (N, c_pad, H, W), the new channels holding `fill` (the code of 0)."""
+    n, c, h, w = codes.shape
+    if c == c_pad:
+        return codes
+    out = torch.full((n, c_pad, h, w), fill, dtype=codes.dtype, device=codes.device).contiguous(memory_format=torch.channels_last)
+    out[:, :c] = codes
+    return out
+
+
+def _weight_codes(node):
+    """Integer weight codes [K, C, R, S] (int16) of a plan node whose spec carries its own quantiser, with codes above 127
+    re-centred (qw - 128, offset + 128 * s: the matrix cores multiply signed bytes)."""
+    q = node._w_codes().to(torch.int16)
+    if q.dim() == 2:
+        q = q[:, :, None, None]
+    if node.w_hi > 127:
+        q = q - 128
+        shift = 128.0 * node.w_scale[:node.k]
+        base = node.w_off[:node.k] if node.w_off is not None else torch.zeros_like(shift)
+        node.w_off = node._padk(base + shift, 0.0)
+    return q
 
 
 class Int8Layer(_PlanLayer):
@@ -144,19 +233,40 @@ class Int8Layer(_PlanLayer):
 
     def __init__(self, layer, spec, **kw):
         super().__init__(layer, spec, **kw)
-        wq, wsum = K.quantize_weight_krsc(layer.weight, self.w_scale, self.w_lo, self.w_hi)
+        w = layer.weight.detach()
+        c = w.shape[1]
+        self.c, self.c_pad = c, (_ceil64(c) if w.dim() == 4 else c)
+        if self._w_codes is None and self.c_pad == c and self.k_pad == self.k:
+            wq, wsum = K.quantize_weight_krsc(w, self.w_scale, self.w_lo, self.w_hi)
+        else:
+            if self._w_codes is not None:
+                q = _weight_codes(self)                                            # [K, C, R, S] int16
+            else:
+                q4 = w if w.dim() == 4 else w[:, :, None, None]
+                q = K.quantize_weight_krsc(q4, self.w_scale[:self.k], self.w_lo, self.w_hi)[0].permute(0, 3, 1, 2).to(torch.int16)
+            full = torch.zeros((self.k_pad, self.c_pad) + tuple(q.shape[2:]), dtype=torch.int16, device=q.device)
+            full[:self.k, :c] = q
+            wq = full.permute(0, 2, 3, 1).contiguous().to(torch.int8)                # KRSC
+            wsum = full.sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
         self.register_buffer("wq", wq, persistent=False)
         self.register_buffer("wsum", wsum, persistent=False)
 
     def _codes(self, x):
-        """The activation codes of `x` (already codes, or fp32 quantised here in one pass)."""
+        """The activation codes of `x` (already codes, or fp32 quantised here in one pass), channel-padded for the kernel."""
         act = self.act
-        if x.dtype in (torch.uint8, torch.int8):
-            return x
-        N.require_gpu(x)
-        if x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
-            x = x.contiguous(memory_format=torch.channels_last)
-        return K.fake_quant(x, act.scale, act.zp, act.lo, act.hi, act.form, g=act.g(x.numel()), codes="i8", want_y=False)[1]
+        if x.dtype not in (torch.uint8, torch.int8):
+            N.require_gpu(x)
+            if x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
+                x = x.contiguous(memory_format=torch.channels_last)
+            x = K.fake_quant(x, act.scale, act.zp, act.lo, act.hi, act.form, g=act.g(x.numel()), codes="i8", want_y=False)[1]
+        c_pad = getattr(self, "c_pad", x.shape[1])
+        if x.dim() == 4 and x.shape[1] != c_pad:
+            x = _pad_channels(x, c_pad, int(0 if act.zp is None else float(act.zp.reshape(-1)[0])))
+        return x
+
+    def _real_numel(self, codes):
+        """Elements of the layer's real (unpadded) input: QBase's grad_scale factor is defined on it."""
+        return codes.numel() // codes.shape[1] * self.c if codes.dim() == 4 else codes.numel()
 
     def _conv_kw(self):
         lay = self.layer
@@ -173,7 +283,7 @@ class Int8Layer(_PlanLayer):
     def operand(self, x):
         """This layer as one addend of conv2d_i8_dual."""
         codes = self._codes(x)
-        return dict(codes=codes, wq=self.wq, wsum=self.wsum, bias=self.layer.bias, in_scale=self._in_scale(codes.numel()),
+        return dict(codes=codes, wq=self.wq, wsum=self.wsum, bias=self._bias(), in_scale=self._in_scale(self._real_numel(codes)),
                     in_zp=self.act.zp, w_scale=self.w_scale, **self._conv_kw())
 
     def forward(self, x, residual=None):
@@ -186,18 +296,46 @@ class Int8Layer(_PlanLayer):
             if residual is not None:
                 residual = residual.reshape(-1, residual.shape[-1])
         codes = self._codes(x)
-        numel = codes.numel()
+        numel = self._real_numel(codes)
         emit = self._emit_for(codes.shape[0], lay.weight.shape[0], *self._out_hw(codes))
         kw = self._conv_kw()
-        if self.relu or residual is not None or emit is not None:
-            res = K.conv2d_i8(codes, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale,
+        if self.w_off is not None:
+            kw["w_offset"] = self.w_off
+        if self.relu or residual is not None or emit is not None or self.w_off is not None:
+            res = K.conv2d_i8(codes, self.wq, self.wsum, self._bias(), self._in_scale(numel), act.zp, self.w_scale,
                               residual=residual, relu=self.relu, emit=emit, want_out=self.want_out, **kw)
             out, out_codes = res if emit is not None else (res, None)
         else:
-            out, out_codes = K.conv2d_i8(codes, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale, **kw), None
+            out, out_codes = K.conv2d_i8(codes, self.wq, self.wsum, self._bias(), self._in_scale(numel), act.zp, self.w_scale, **kw), None
         if lead is not None:
             out = None if out is None else out.reshape(*lead, out.shape[-1])
             out_codes = None if out_codes is None else out_codes.reshape(*lead, out_codes.shape[-1])
+        return self._finish(out, out_codes)
+
+
+class DwInt8Layer(Int8Layer):
+    """A depthwise convolution of the frozen plan (csrc/conv_dw_i8.hip): codes in, codes (and / or fp32) out."""
+
+    def __init__(self, layer, spec, **kw):
+        _PlanLayer.__init__(self, layer, spec, **kw)
+        w = layer.weight.detach()
+        self.c, self.c_pad = self.k, self.k_pad
+        if self._w_codes is not None:
+            q = _weight_codes(self)                                                # [C, 1, R, S]
+        else:
+            q = K.quantize_weight_krsc(w, self.w_scale[:self.k], self.w_lo, self.w_hi)[0].permute(0, 3, 1, 2).to(torch.int16)
+        full = torch.zeros((self.k_pad,) + tuple(q.shape[2:]), dtype=torch.int16, device=q.device)
+        full[:self.k] = q[:, 0]
+        self.register_buffer("wq", full.permute(1, 2, 0).contiguous().to(torch.int8), persistent=False)   # [R, S, C]
+
+    def forward(self, x):
+        lay, act = self.layer, self.act
+        codes = self._codes(x)
+        numel = self._real_numel(codes)
+        emit = self._emit_for(codes.shape[0], self.k, *self._out_hw(codes))
+        res = K.conv2d_dw_i8(codes, self.wq, self._bias(), self._in_scale(numel), act.zp, self.w_scale, self.w_off,
+                             stride=lay.stride[0], padding=lay.padding[0], relu=self.relu, emit=emit, want_out=self.want_out)
+        out, out_codes = res if emit is not None else (res, None)
         return self._finish(out, out_codes)
 
 
@@ -340,7 +478,7 @@ def fuse_inference(model, report=None, dry_run=False):
             acts = {dual_inputs[u][i].key: dual_inputs[u][i] for i in (0, 1) if u.args[i] is t}
             return next(iter(acts.values())) if len(acts) == 1 else None
         s = spec_of(u) if u.args and u.args[0] is t else None
-        return s[0] if s is not None and s[4] == "gemm" else None
+        return s[0] if s is not None and s[4] in ("gemm", "dw") else None
 
     count = 0
     live = set(graph.nodes)
@@ -397,10 +535,10 @@ def fuse_inference(model, report=None, dry_run=False):
         count += 1
         specs[name] = None
         modules[name] = None
-        cls = Int8Layer if spec[4] == "gemm" else StemLayer
+        cls = {"gemm": Int8Layer, "dw": DwInt8Layer}.get(spec[4], StemLayer)
         # the shortcut is itself a not-yet-planned int8 convolution read by nobody else: one dual kernel
         other = spec_of(residual) if residual is not None and residual.op == "call_module" else None
-        dual = (other is not None and other[4] == "gemm" and list(residual.users) == [chain[1]] and
+        dual = (other is not None and other[4] == "gemm" and spec[5] is None and other[5] is None and list(residual.users) == [chain[1]] and
                 modules[node.target].weight.dim() == 4 and modules[residual.target].weight.dim() == 4)
         if dry_run:       # decisions only (CPU-side tests): the node is a placeholder, nothing is quantised or launched
             gm.add_module(name, _DryNode())

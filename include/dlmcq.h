@@ -335,6 +335,30 @@ int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float* out, const
                                const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
                                int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
 
+/* dlmcq_conv2d_i8_nhwc_fused for ASYMMETRIC per-output-channel weights (ops.py:129-136, unsigned `minmax_channel`:
+ * w' = qw * s_w[k] + o_w[k], the offset being the channel minimum; BASELINE configs[4], W4A8): the convolution gains the
+ * term  o_w[k] * SUM x'  over the receptive field, which the kernel evaluates from a per-pixel sum of the activation
+ * codes (v_dot4_i32_i8 on the operand fragments it multiplies anyway):
+ *     out = s_in * ( s_w[k] * (SUM q'*qw + (shift - zp) * SUM qw)  +  o_w[k] * SUM (q - zp) ) + bias[k].
+ * `w` holds int8 codes; codes above 127 (8-bit unsigned weights) are stored minus 128 with w_offset += 128 * s_w[k]. */
+int dlmcq_conv2d_i8_nhwc_asym(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                              const float* in_scale, const float* in_zero_point, const float* w_scale, const float* w_offset,
+                              int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride,
+                              int32_t pad, int32_t dilation, int32_t x_is_unsigned, const float* residual, int32_t relu,
+                              void* codes, const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
+                              int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
+
+/* Depthwise 3x3 convolution (groups = channels; the MobileOne / MobileNet unit, modules/conv.py:13-19 with `groups`) on
+ * activation codes, HBM-bound (1 byte in, 1 byte out): plain vector arithmetic, no matrix cores.  x: NHWC codes (uint8 if
+ * x_is_unsigned), C % 4 == 0; w: int8 codes [R*S][C] (tap-major); per-channel w_scale and optional w_offset (asymmetric
+ * weights as above), bias; zero padding (x' = 0).  Epilogue as dlmcq_conv2d_i8_nhwc_fused: ReLU, fp32 NHWC out and / or the
+ * consumer's codes.   out = s_in * ( s_w[c] * SUM (q - zp) * qw  +  o_w[c] * SUM (q - zp) ) + bias[c]   (exact integer sums). */
+int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* out, const float* bias, const float* in_scale,
+                            const float* in_zero_point, const float* w_scale, const float* w_offset, int64_t N, int64_t H,
+                            int64_t W, int64_t C, int64_t R, int64_t S, int32_t stride, int32_t pad, int32_t x_is_unsigned,
+                            int32_t relu, void* codes, const float* q_scale, const float* q_zero_point, int32_t q_lo,
+                            int32_t q_hi, int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
+
 /*
  * Two convolutions into ONE output: out = conv(x, w) + conv(x2, w2), each dequantised with its own scales and bias
  * and summed in fp32 (one addition, as `out += identity` does it in a residual block whose shortcut is a

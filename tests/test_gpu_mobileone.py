@@ -1,0 +1,125 @@
+"""BASELINE configs[4]: MobileOne-S1 W4A8, asymmetric per-channel weights (ops.py:129-136: unsigned `minmax_channel`, the
+offset is the channel minimum), 8-bit unsigned per-tensor activations - on the int8 kernels of the frozen plan:
+depthwise 3x3 layers on csrc/conv_dw_i8.hip, pointwise 1x1 layers on the matrix cores with the weight-offset term of
+dlmcq_conv2d_i8_nhwc_asym, 96-channel tensors zero-padded to 128.  Every plan node is checked against the float64
+reference of tests/plan_reference.py computed from ITS OWN input (no drift): fp32 to rtol 2e-6 of the summed magnitude,
+codes exact from the kernel's own fp32 value and within one code on < 1e-3 of the elements otherwise."""
+import json
+
+import pytest
+import torch
+
+from plan_reference import close, emit_codes, node_window_ref, weight_dequant
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+W4A8 = {  # QBase family (quantization_type=None), per-channel extension
+    "weight": {"enable": True, "type": "minmax_channel", "args": {"n_bits": 4, "signed": False}},
+    "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+    "exclude_layers": [], "override_options": [],
+}
+
+
+def _check_node(idx, mod, args, out, full):
+    from dlmc.utils.fuse import DwInt8Layer
+    fp32, codes = out
+    o = fp32 if fp32 is not None else codes
+    if o.dim() == 2:
+        fp32 = None if fp32 is None else fp32[:, :, None, None]
+        codes = None if codes is None else codes[:, :, None, None]
+        o = o[:, :, None, None]
+    lay = mod.layer
+    k = mod.k
+    n_img, _, P, Q = o.shape
+    w_deq = weight_dequant(mod)
+    bias = None if lay.bias is None else lay.bias.detach().float().cpu()
+    dw = isinstance(mod, DwInt8Layer)
+    stride, pad = (lay.stride[0], lay.padding[0]) if lay.weight.dim() == 4 else (1, 0)
+    xin = args[0] if args[0].dim() == 4 else args[0][:, :, None, None]
+    xin = xin[:, :mod.c]                                     # drop the padding channels
+    numel = xin.numel()
+    if xin.dtype == torch.float32:                           # fed by a layer outside the plan: the node quantises its input itself
+        xin = emit_codes(mod.act, xin.float().cpu(), numel).to(torch.uint8)
+    wins = [(n, 0, 0, P, Q) for n in range(n_img)] if full else \
+        [(n, p0, q0, min(5, P), min(5, Q)) for n in (0, n_img - 1) for p0, q0 in ((0, 0), (P - min(5, P), Q - min(5, Q)))]
+    emit_numel = n_img * k * P * Q
+    for win in wins:
+        n, p0, q0, ph, qw = win
+        ref, mag = node_window_ref(xin, mod.act, numel, w_deq, bias, stride, pad, k if dw else 1, win)
+        ref = torch.relu(ref) if mod.relu else ref
+        what = f"node {idx} {type(mod).__name__} {tuple(lay.weight.shape)} window {win}"
+        got32 = None
+        if fp32 is not None:
+            got32 = fp32[n:n + 1, :k, p0:p0 + ph, q0:q0 + qw].cpu()
+            close(got32, ref, mag, what)
+        if codes is not None:
+            got = codes[n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu()
+            if got.shape[1] > k:      # padding channels: the consumer's code of 0
+                pad_code = emit_codes(mod.emit, torch.zeros(1), emit_numel)
+                assert bool((got[:, k:].float() == float(pad_code)).all()), f"{what}: padding channels"
+            if got32 is not None:
+                assert torch.equal(got[:, :k].float(), emit_codes(mod.emit, got32, emit_numel)), f"{what}: codes of the kernel's own fp32 value"
+            else:
+                off = (got[:, :k].float() - emit_codes(mod.emit, ref.float(), emit_numel)).abs()
+                assert float(off.max()) <= 1 and float((off > 0).float().mean()) < 2e-3, \
+                    f"{what}: codes off by {float(off.max())} on {float((off > 0).float().mean()):.2e} of the elements"
+
+
+@pytest.mark.parametrize("batch,size,full", [(3, 64, True), (64, 224, False)])
+def test_mobileone_s1_w4a8_plan_node_by_node(batch, size, full):
+    import workloads as W
+    from dlmc.utils.fuse import DwInt8Layer, Int8Layer, fuse_inference
+    from dlmc.utils.quantize import quantize_model
+    torch.manual_seed(2333)
+    net = W.mobileone_s1_deploy().to(DEV).eval()
+    quantize_model(net, json.loads(json.dumps(W4A8)), None)
+    x = torch.relu(torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(5))).to(DEV)
+    recs = []
+    with torch.no_grad():
+        want = net(x)                       # calibrates; the module path (fp32 convolutions of the fake-quantised operands)
+        plan = fuse_inference(net)
+        rep = plan.fusion_report
+        for m in plan.modules():
+            if isinstance(m, Int8Layer):
+                m.register_forward_hook(lambda mod, args, out: recs.append((mod, args, out)))
+        got = plan(x)
+    n_dw = sum(isinstance(r[0], DwInt8Layer) for r in recs)
+    assert n_dw == 21 and len(recs) == 21 + 21 + 1, (n_dw, len(recs), rep)     # 21 units + the classifier; the stem is below
+    assert rep.skipped in ([], ["stage0.0"]), rep
+    for idx, (mod, args, out) in enumerate(recs):
+        if mod.layer.weight.dim() == 2:
+            continue                         # the classifier reads fp32 features: checked through the logits below
+        _check_node(idx, mod, args, out, full)
+    # logits against the module path: same codes layer by layer up to fp32 accumulation-order ties
+    spread = float(want.std())
+    assert float((got - want).abs().mean()) < 0.05 * spread and torch.equal(got.argmax(1), want.argmax(1)) or batch > 8
+
+
+def test_depthwise_kernel_shapes_and_forms():
+    """conv2d_dw_i8 alone: strides, paddings, 5x5 taps, signed codes, symmetric and asymmetric weights, a zero point."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    import torch.nn.functional as F
+    for idx, (n, c, h, w, r, stride, pad, signed, asym) in enumerate([(2, 64, 9, 9, 3, 1, 1, False, True), (3, 8, 12, 7, 3, 2, 1, False, False),
+                                                                      (1, 192, 14, 14, 5, 1, 2, True, True), (2, 12, 6, 6, 3, 1, 0, False, True)]):
+        g = torch.Generator().manual_seed(40 + idx)
+        lo, hi = (-127, 127) if signed else (0, 255)
+        codes = torch.randint(lo, hi + 1, (n, c, h, w), generator=g).to(torch.int8 if signed else torch.uint8)
+        zp = 0.0 if signed else 4.0
+        qw = torch.randint(0, 16, (c, 1, r, r), generator=g)
+        s_w = torch.rand(c, generator=g) * 0.02 + 0.001
+        o_w = (torch.randn(c, generator=g) * 0.05) if asym else None
+        bias = torch.randn(c, generator=g)
+        s_in = 0.03
+        xd = (codes.double() - zp) * s_in
+        wd = qw.double() * s_w.double().reshape(-1, 1, 1, 1) + (o_w.double().reshape(-1, 1, 1, 1) if asym else 0)
+        ref = torch.relu(F.conv2d(xd, wd, bias.double(), stride=stride, padding=pad, groups=c))
+        mag = F.conv2d(xd.abs(), wd.abs(), bias.double().abs(), stride=stride, padding=pad, groups=c)
+        emit = K.EmitCodes(torch.tensor([float(ref.max()) / 255 + 1e-3], device=DEV), torch.tensor([2.0], device=DEV), 0, 255, N.FORM_ZEROPOINT)
+        out, oc = K.conv2d_dw_i8(codes.to(DEV).contiguous(memory_format=torch.channels_last), qw[:, 0].permute(1, 2, 0).contiguous().to(torch.int8).to(DEV),
+                                 bias.to(DEV), torch.tensor([s_in], device=DEV), torch.tensor([zp], device=DEV), s_w.to(DEV),
+                                 None if o_w is None else o_w.to(DEV), stride=stride, padding=pad, relu=True, emit=emit)
+        close(out.cpu(), ref, mag, f"dw case {idx}")
+        from oracle import fakequant_oracle as O
+        assert torch.equal(oc.cpu().float(), O.fq_zeropoint(out.cpu(), emit.scale.cpu(), emit.zero_point.cpu(), 0, 255)[0]), f"dw case {idx} codes"

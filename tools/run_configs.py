@@ -121,11 +121,22 @@ def main():
             del m, x
             torch.cuda.empty_cache()
     # ---- config 5
-    m = W.mobileone_s1_deploy().to(DEV).eval()
-    quantize_model(m, cfg("minmax_channel", 4, False, 8, False, False), None)
-    x = torch.randn(1024, 3, 224, 224, device=DEV)
-    dt, fam = time_model(m, x, 5)
-    out["config5_mobileone_s1_b1024_w4a8"] = {"ms_per_step": round(dt * 1e3, 2), "images_per_s": round(1024 / dt, 1), "kernels": fam}
+    # W4A8, asymmetric per-channel weights (QBase family): the reference's own op sequence (fp32 convolutions of the
+    # fake-quantised operands, module by module) and the frozen plan (depthwise layers on conv_dw_i8.hip, pointwise layers on the
+    # matrix cores with the weight-offset term, 96-channel tensors padded to 128; the 3-channel first layer stays fp32)
+    for mode in ("fp32conv_modules", "fused_plan"):
+        m = W.mobileone_s1_deploy().to(DEV).eval()
+        quantize_model(m, cfg("minmax_channel", 4, False, 8, False, False), None)
+        x = torch.relu(torch.randn(1024, 3, 224, 224, device=DEV))         # unsigned-activation configs
+        with torch.no_grad():
+            m(x)
+            if mode == "fused_plan":
+                from dlmc.utils.fuse import fuse_inference
+                m = fuse_inference(m)
+        dt, fam = time_model(m, x, 5)
+        out[f"config5_mobileone_s1_b1024_w4a8_{mode}"] = {"ms_per_step": round(dt * 1e3, 2), "images_per_s": round(1024 / dt, 1), "kernels": fam}
+        del m, x
+        torch.cuda.empty_cache()
     print(json.dumps(out, indent=1))
 
 
