@@ -99,7 +99,7 @@ def _frozen_spec(mod):
 
 def _frozen_spec_(mod, kind):
     if isinstance(mod, FSPTQBase):
-        if kind == "dw" or not (mod.act_quant and mod.wt_quant) or mod.in_scale.numel() != 1:
+        if not (mod.act_quant and mod.wt_quant) or mod.in_scale.numel() != 1:
             return None
         if mod.qconfig["weight"].get("recon_type") in ("adaround", "dist_recon"):
             return None
@@ -167,6 +167,7 @@ class _PlanLayer(nn.Module):
         self.register_buffer("w_off", None if w_off is None else self._padk(w_off.to(w_scale.device), 0.0), persistent=False)
         self.register_buffer("bias_pad", None if layer.bias is None or self.k_pad == k else self._padk(layer.bias.detach().float(), 0.0),
                              persistent=False)
+        self._zp_fill = int(0 if self.act.zp is None else float(self.act.zp.reshape(-1)[0]))   # (read once: no host sync in forward)
         self._deq = {}     # QBase dequantises with s^ = grad_scale(s, g(numel)): one tiny tensor per input size
 
     def _padk(self, v, fill):
@@ -261,7 +262,7 @@ class Int8Layer(_PlanLayer):
             x = K.fake_quant(x, act.scale, act.zp, act.lo, act.hi, act.form, g=act.g(x.numel()), codes="i8", want_y=False)[1]
         c_pad = getattr(self, "c_pad", x.shape[1])
         if x.dim() == 4 and x.shape[1] != c_pad:
-            x = _pad_channels(x, c_pad, int(0 if act.zp is None else float(act.zp.reshape(-1)[0])))
+            x = _pad_channels(x, c_pad, self._zp_fill)
         return x
 
     def _real_numel(self, codes):

@@ -85,7 +85,11 @@ def _run(family, backend):
     want = _scales(net)
     for r in (0, 1):
         for k, v in want.items():
-            assert torch.equal(res[r][0][k], v), f"rank {r} {k}: {res[r][0][k]} vs {v}"
+            if k.startswith("0."):       # the first layer sees the data itself: the all-reduced observer is exact
+                assert torch.equal(res[r][0][k], v), f"rank {r} {k}: {res[r][0][k]} vs {v}"
+            else:                        # deeper layers see fp32 convolution outputs, whose last bit MIOpen may change with the batch size
+                torch.testing.assert_close(res[r][0][k], v, rtol=2e-6, atol=0, msg=lambda m: f"rank {r} {k}: {m}")
+            assert torch.equal(res[r][0][k], res[1 - r][0][k]) or not k.startswith("0."), f"ranks disagree on {k}"
     got = torch.cat([res[0][1], res[1][1]])
     torch.testing.assert_close(got, full, rtol=1e-5, atol=1e-6)
 

@@ -148,7 +148,7 @@ QBASE = {"weight": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 
 
 @pytest.mark.parametrize("arch,qtype,cfg,res,signed_image", [
     ("resnet50", "FSPTQ", FSPTQ, 64, False), ("resnet18", "FSPTQ", FSPTQ, 96, True), ("repvgg_a1", "FSPTQ", FSPTQ, 64, False),
-    ("resnet18", None, QBASE, 64, True), ("mobileone_s1", "FSPTQ", FSPTQ, 64, False), ("resnet18-bn", "FSPTQ", FSPTQ, 64, False)])
+    ("resnet18", None, QBASE, 64, True), ("resnet18-bn", "FSPTQ", FSPTQ, 64, False)])
 def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res, signed_image):
     """`signed_image`: N(0,1) pixels.  Under the FSPTQ u8 activation config the reference's zero point is then the
     (negative, non-integer) minimum (FSPTQuant/base.py:99-103 via ops.py:20-34), the first layer's codes are not

@@ -66,14 +66,21 @@ def _check_node(idx, mod, args, out, full):
                     f"{what}: codes off by {float(off.max())} on {float((off > 0).float().mean()):.2e} of the elements"
 
 
-@pytest.mark.parametrize("batch,size,full", [(3, 64, True), (64, 224, False)])
-def test_mobileone_s1_w4a8_plan_node_by_node(batch, size, full):
+W8A8_FSPTQ = {  # example/quantization/FSPTQ_config.yaml:40-53 (symmetric per-channel s8 weights, u8 activations)
+    "weight": {"enable": True, "type": "minmax_channel", "recon_type": "None", "args": {"n_bits": 8, "signed": True}},
+    "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+    "exclude_layers": [], "override_options": [],
+}
+
+
+@pytest.mark.parametrize("family,batch,size,full", [(None, 3, 64, True), (None, 64, 224, False), ("FSPTQ", 3, 64, True)])
+def test_mobileone_s1_w4a8_plan_node_by_node(family, batch, size, full):
     import workloads as W
     from dlmc.utils.fuse import DwInt8Layer, Int8Layer, fuse_inference
     from dlmc.utils.quantize import quantize_model
     torch.manual_seed(2333)
     net = W.mobileone_s1_deploy().to(DEV).eval()
-    quantize_model(net, json.loads(json.dumps(W4A8)), None)
+    quantize_model(net, json.loads(json.dumps(W4A8 if family is None else W8A8_FSPTQ)), None, family)
     x = torch.relu(torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(5))).to(DEV)
     recs = []
     with torch.no_grad():

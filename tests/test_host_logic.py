@@ -183,7 +183,7 @@ def test_fusion_decisions_without_a_gpu():
     rep = fuse_inference(calibrated(W.repvgg_a1_deploy()), dry_run=True).fusion_report
     assert (rep.layers, rep.stem, rep.relu, rep.emit, rep.fp32_outputs, rep.dual) == (23, 1, 22, 21, 2, 0)
     rep = fuse_inference(calibrated(W.mobileone_s1_deploy()), dry_run=True).fusion_report
-    assert rep.stem == 1 and len(rep.skipped) == 23 and all(n.endswith(".dw") or n.endswith(".pw") for n in rep.skipped)
+    assert (rep.stem, rep.layers, rep.skipped) == (1, 44, [])        # depthwise layers and 96-channel pointwise layers (padded) included
     with pytest.raises(RuntimeError):
         fuse_inference(calibrated(W.resnet18()).train(), dry_run=True)
 
