@@ -41,7 +41,7 @@ namespace dlmcq {
 //   * everything the epilogue needs from memory (per-channel scale / code sum / bias of both pairs and, for 64-wide
 //     tiles, the fp32 shortcut tile) is requested BEFORE the first operand, so that a tile pays one memory round trip,
 //     not four in a row: at ResNet sizes most tiles have 1-8 K steps and their lifetime is latency, not work.
-template <int BN, bool DUAL, bool ADIR, bool ASYM = false>
+template <int BN, bool DUAL, bool ADIR, bool ASYM = false, bool STAMP = false>
 __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ bias,
     const int32_t* __restrict__ wsum, const float* __restrict__ s_in, const float* __restrict__ zp_in,
@@ -233,8 +233,17 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 6
   static_for<PF>([&](auto i) {
     if (decltype(i)::value < nsteps) issue_next(i);
   });
+  // STAMP (lab builds only): one wave of a workgroup in the middle of the grid writes the shader clock at the phase
+  // boundaries of its first 24 K steps into the buffer passed as ep.residual (which is then not used as a shortcut)
+  unsigned long long* trace = nullptr;
+  if (STAMP && blockIdx.x == gridDim.x / 2 && tid == 0) trace = (unsigned long long*)ep.residual;
+  if (STAMP) ep.residual = nullptr;
+  auto stamp = [&](int step, int k) {
+    if (STAMP && trace && step < 24) trace[step * 8 + k] = __builtin_readcyclecounter();
+  };
   auto one_step = [&](int step, auto slot_c) {
     constexpr int U = decltype(slot_c)::value;          // ring slot of this step; step + PF goes to slot (U + PF) % NBUF
+    stamp(step, 0);
     // step's own loads must have landed; the younger group stays in flight
     if (step + PF - 1 < nsteps) {
       static_assert(PF == 2, "vmcnt immediates below");
@@ -245,10 +254,15 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 6
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last step
     }
+    stamp(step, 1);
     __builtin_amdgcn_s_barrier();                 // everyone's step-k bytes are in LDS; everyone left multiply(k-1)
+    stamp(step, 2);
     if constexpr (ADIR)   // the asm-loaded A fragments of this step are valid from here on (orders their uses behind the wait)
       asm volatile("" : "+v"(areg[ADIR ? U : 0][0]), "+v"(areg[ADIR ? U : 0][1]));
+    // (issuing the next loads BEHIND this step's MFMAs - which execute meanwhile - was measured: the operands then arrive
+    //  late, +3 % per step; reading all fragments of a step before its first MFMA: no difference)
     if (step + PF < nsteps) issue_next(std::integral_constant<int, (U + PF) % NBUF>{});  // the slot multiply(k-1) released
+    stamp(step, 3);
     if (DUAL && step == nfirst) {
       // the shortcut pair is complete: dequantise its sum into registers and start the layer's own sum from zero
       const float sin2 = sg.s_in[0];
@@ -288,6 +302,10 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 6
         const i32x4 bf = *reinterpret_cast<const i32x4*>(base + TILE_A + brow * BK + ((sg_ ^ ((brow >> 2) & 3)) << 4));
         acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[j], 0, 0, 0);
       }
+    }
+    if (STAMP) {
+      asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[NT - 1][15]));
+      stamp(step, 4);
     }
   };
   for (int s0 = 0; s0 < nsteps; s0 += NBUF)
@@ -608,6 +626,28 @@ extern "C" int dlmcq_conv2d_i8_nhwc_dual(const void* x, const int8_t* w, float* 
 }
 
 #ifdef DLMCQ_LAB
+// phase stamps of one wave (tools/conv_trace.py): `trace` receives 24 x 8 uint64 shader-clock values
+extern "C" int dlmcq_x_conv2d_i8_trace(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                                       const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N,
+                                       int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride,
+                                       int32_t pad, int32_t dilation, int32_t x_is_unsigned, void* codes, const float* q_scale,
+                                       dlmcq_stream_t stream, void* trace) {
+  ConvEpi ep = make_epi(static_cast<const float*>(trace), 1, codes, q_scale, nullptr, 0, 255, DLMCQ_FORM_ZEROPOINT, 0.0f);
+  const int64_t P = (H + 2 * pad - dilation * (R - 1) - 1) / stride + 1, Q = (W + 2 * pad - dilation * (S - 1) - 1) / stride + 1;
+  if (C % CV_BK || K % 128 || P < 1 || Q < 1) return DLMCQ_EINVAL;
+  ConvGeom g;
+  g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C = (int)C; g.K = (int)K; g.R = (int)R; g.S = (int)S;
+  g.stride = stride; g.pad = pad; g.dil = dilation; g.P = (int)P; g.Q = (int)Q; g.M = N * P * Q;
+  g.qdiv = make_fastdiv((uint32_t)Q);
+  g.pdiv = make_fastdiv((uint32_t)P);
+  g.nblk_m = (int)((g.M + CV_BM - 1) / CV_BM);
+  g.nblk_n = (int)(K / 128);
+  hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, false, true>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const int8_t*>(x), w, out, bias, wsum, in_scale,
+                     in_zero_point, w_scale, g, x_is_unsigned ? 128 : 0, ep, ConvSeg2{});
+  return launch_status();
+}
+
 // ---- lab library only (libdlmcq_lab.so, `make lab`): the same calls with an explicit tile plan, and the persistent
 // kernel of lab/conv_i8_pp.hip, for A/B measurements in one process (tools/conv_lab.py).  Not part of the ABI. ----
 int dlmcq_conv_pp_launch(const int8_t* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,

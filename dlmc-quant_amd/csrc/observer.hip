@@ -175,15 +175,16 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void minmax_rows_kernel(const float* _
             if (on && n + k < n_hi) acc_add4<MODE>(a, v[k]);
         }
       } else {
+        constexpr int UF = TEAM == DLMCQ_WAVE ? 8 : 4;     // loads in flight per lane (one-wave teams: deeper)
         for (int64_t n = n_lo; n < n_hi; ++n) {
           const f32x4* __restrict__ r4 = reinterpret_cast<const f32x4*>(x + n * rstride + c * inner);
-          for (int64_t i = lane; i < i4; i += 4 * TEAM) {
-            f32x4 v[4];
+          for (int64_t i = lane; i < i4; i += UF * TEAM) {
+            f32x4 v[UF];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < UF; ++k)
               if (i + k * TEAM < i4) v[k] = __builtin_nontemporal_load(r4 + i + k * TEAM);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < UF; ++k)
               if (i + k * TEAM < i4) acc_add4<MODE>(a, v[k]);
           }
         }
@@ -345,7 +346,7 @@ static Plan make_plan(int64_t outer, int64_t channels, int64_t inner) {
     return p;
   }
   p.per_tensor = false;
-  p.team = (inner <= 1024) ? DLMCQ_WAVE : DLMCQ_BLOCK;
+  p.team = (inner <= 16384) ? DLMCQ_WAVE : DLMCQ_BLOCK;   // one-wave teams stream best (tools/tune_fq.hip); whole blocks only for very long rows
   const int tpb = DLMCQ_BLOCK / p.team;
   p.grid_x = (int)((channels + tpb - 1) / tpb);
   // split `outer` so that enough teams exist to fill the chip, at >= 1 row per segment
