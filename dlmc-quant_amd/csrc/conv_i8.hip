@@ -42,7 +42,7 @@ namespace dlmcq {
 //     tiles, the fp32 shortcut tile) is requested BEFORE the first operand, so that a tile pays one memory round trip,
 //     not four in a row: at ResNet sizes most tiles have 1-8 K steps and their lifetime is latency, not work.
 template <int BN, bool DUAL, bool ADIR, bool ASYM = false, bool STAMP = false>
-__global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 3) : (ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
+__global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ bias,
     const int32_t* __restrict__ wsum, const float* __restrict__ s_in, const float* __restrict__ zp_in,
     const float* __restrict__ s_w, ConvGeom g, int shift, ConvEpi ep, ConvSeg2 sg) {

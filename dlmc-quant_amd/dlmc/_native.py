@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdlmcq.so")
+LIB_PATH = os.environ.get("DLMCQ_LIBRARY") or os.path.join(os.path.dirname(_HERE), "libdlmcq.so")   # (override: A/B builds, tools/)
 
 # enums of include/dlmcq.h
 FORM_EMULATE, FORM_QBASE, FORM_ZEROPOINT, FORM_SYMMETRIC, FORM_ROOTQ_ACT = range(5)

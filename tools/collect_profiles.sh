@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects the round's measurement artefacts on the GPU box into gpurun_out/prof_rNN/ (copy what is to be judged into profiles/).
+# usage: tools/collect_profiles.sh r02
+set -e
+R=${1:-rNN}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="$GRAFT_REPO_ROOT/bench.py"
+python3 "$B" --steps 20 --warmup 5 > "$OUT/bench_line.json" 2> "$OUT/bench.err"
+python3 "$B" --steps 20 --warmup 5 --streams 1 --no-cpu-baseline > "$OUT/bench_line_streams1.json" 2>> "$OUT/bench.err"
+# per-kernel durations of the same command (one stream: rocprofv3 and the HIP events then describe the same thing)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python3 "$B" --steps 20 --warmup 5 --streams 1 --no-cpu-baseline > "$OUT/stats.log" 2>&1 || echo "stats pass failed"
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/fetch.log" 2>&1 || echo "fetch pass failed"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/write.log" 2>&1 || echo "write pass failed"
+cd "$GRAFT_REPO_ROOT"
+python3 tools/pmc_summary.py --tail conv_i8_mfma_kernel 49 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
+python3 tools/plan_profile.py resnet50 512 > "$OUT/plan_profile_resnet50_b512.txt" 2>&1
+python3 tools/conv_lab.py --knobs 128:1,64:1,128:0,64:0 > "$OUT/conv_lab_resnet50_layers.txt" 2>&1
+python3 tools/conv_trace.py 512 256 14 256 3 > "$OUT/conv_trace_3x3_256_14.txt" 2>&1
+python3 tools/kernel_bench.py > "$OUT/kernel_bench_config2.txt" 2>&1
+python3 tools/run_configs.py > "$OUT/configs_1_3_4_5.json" 2> "$OUT/configs.err"
+find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
+ls -la "$OUT"
