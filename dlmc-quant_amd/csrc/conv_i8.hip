@@ -41,12 +41,15 @@ namespace dlmcq {
 //   * everything the epilogue needs from memory (per-channel scale / code sum / bias of both pairs and, for 64-wide
 //     tiles, the fp32 shortcut tile) is requested BEFORE the first operand, so that a tile pays one memory round trip,
 //     not four in a row: at ResNet sizes most tiles have 1-8 K steps and their lifetime is latency, not work.
-template <int BN, bool DUAL, bool ADIR, bool ASYM = false, bool STAMP = false>
+template <int BN, bool DUAL, bool ADIR, bool ASYM = false, int LAB = 0>
 __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ bias,
     const int32_t* __restrict__ wsum, const float* __restrict__ s_in, const float* __restrict__ zp_in,
     const float* __restrict__ s_w, ConvGeom g, int shift, ConvEpi ep, ConvSeg2 sg) {
   constexpr int BM = CV_BM, BK = CV_BK, NBUF = 3, PF = NBUF - 1;
+  // LAB (lab library only): 1 = clock stamps; 2 = no A loads, 3 = no B loads, 4 = no MFMAs, 5 = all lanes load one A address
+  // (what-bounds-the-step experiments: results are garbage, only the time means something)
+  constexpr bool STAMP = LAB == 1;
   constexpr int TILE_A = ADIR ? 0 : BM * BK, TILE_B = BN * BK, TILE = TILE_A + TILE_B;
   constexpr int KS = BK / 32;           // MFMA K chunks per step
   constexpr int NT = BN / 32;           // 32-column slabs per wave
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
 
   // XCD-aware tile order: the workgroups that share an activation tile (same row block, different column blocks) are
   // consecutive in `tile`, and consecutive tiles are dealt to the SAME XCD (its L2 then serves the re-reads)
+  const unsigned long long t_start = STAMP ? __builtin_readcyclecounter() : 0ull;
   const uint32_t nwg = gridDim.x;
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t qd = nwg >> 3, rm = nwg & 7u;
@@ -172,18 +176,29 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
     retap(f, gg);
   };
   i32x4 areg[ADIR ? NBUF : 1][KS];   // ADIR: the A fragments of the steps in flight
+  if (LAB == 2)
+    for (auto& a3 : areg)
+      for (auto& a : a3) a = i32x4{lane, 1, 2, 3};
   auto issue = [&](Feed& f, const ConvGeom& gg, auto slot_c) {
     constexpr int SL = decltype(slot_c)::value;
     int8_t* base = lds + SL * TILE;
     // B first: its DMA lands in LDS and is awaited by the whole workgroup
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)f.bp[i], (lptr_t)(base + TILE_A + (i * 4 + wave) * 1024), 16, 0, 0);
+      if (LAB != 3) __builtin_amdgcn_global_load_lds((gptr_t)f.bp[i], (lptr_t)(base + TILE_A + (i * 4 + wave) * 1024), 16, 0, 0);
       f.bp[i] += f.b_inc[i];
     }
     if (ADIR) {
-      gload16<0>(areg[ADIR ? SL : 0][0], f.ap[0]);
-      gload16<32>(areg[ADIR ? SL : 0][1], f.ap[0]);
+      if (LAB == 5) {
+        const uint64_t pa = (uint64_t)f.ap[0];
+        const int8_t* pu = (const int8_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)pa));
+        gload16<0>(areg[ADIR ? SL : 0][0], pu);
+        gload16<32>(areg[ADIR ? SL : 0][1], pu);
+      } else if (LAB != 2) {
+        gload16<0>(areg[ADIR ? SL : 0][0], f.ap[0]);
+        gload16<32>(areg[ADIR ? SL : 0][1], f.ap[0]);
+      }
       f.ap[0] += f.a_inc[0];
     } else {
 #pragma unroll
@@ -237,6 +252,15 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
   // boundaries of its first 24 K steps into the buffer passed as ep.residual (which is then not used as a shortcut)
   unsigned long long* trace = nullptr;
   if (STAMP && blockIdx.x == gridDim.x / 2 && tid == 0) trace = (unsigned long long*)ep.residual;
+  // ... and wave 0 of EVERY workgroup its start / K loop entered / K loop left / end clocks (6 values per workgroup behind those, with HW_ID and XCC_ID)
+  unsigned long long* wgt = nullptr;
+  if (STAMP && tid == 0) {
+    wgt = (unsigned long long*)ep.residual + 24 * 8 + 6 * (size_t)blockIdx.x;
+    wgt[0] = t_start;
+    wgt[1] = __builtin_readcyclecounter();
+    wgt[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));     // HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]
+    wgt[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));    // XCC_ID
+  }
   if (STAMP) ep.residual = nullptr;
   auto stamp = [&](int step, int k) {
     if (STAMP && trace && step < 24) trace[step * 8 + k] = __builtin_readcyclecounter();
@@ -300,7 +324,8 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
       for (int j = 0; j < NT; ++j) {
         const int brow = j * 32 + l31;
         const i32x4 bf = *reinterpret_cast<const i32x4*>(base + TILE_A + brow * BK + ((sg_ ^ ((brow >> 2) & 3)) << 4));
-        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[j], 0, 0, 0);
+        if (LAB == 4) asm volatile("" ::"v"(af), "v"(bf));
+        else acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[j], 0, 0, 0);
       }
     }
     if (STAMP) {
@@ -313,6 +338,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
       if (s0 + decltype(u)::value < nsteps) one_step(s0 + decltype(u)::value, u);
     });
 
+  if (STAMP && wgt) wgt[2] = __builtin_readcyclecounter();
   // ---- epilogue: one rounding chain  v = (acc + (shift - zp) * SUM qw) * (s_in * s_w[k]) + b[k] ----
   const float sin = s_in[0];
   const EpiQuant eq(ep);
@@ -377,6 +403,10 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the stage
     });
+    if (STAMP && wgt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wgt[3] = __builtin_readcyclecounter();
+    }
     return;
   }
   // K % 4 != 0 (e.g. a 1000-class head): element-wise stores straight from the accumulator layout
@@ -647,7 +677,7 @@ extern "C" int dlmcq_x_conv2d_i8_trace(const void* x, const int8_t* w, float* ou
   g.pdiv = make_fastdiv((uint32_t)P);
   g.nblk_m = (int)((g.M + CV_BM - 1) / CV_BM);
   g.nblk_n = (int)(K / 128);
-  hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, false, true>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0,
+  hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, false, 1>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const int8_t*>(x), w, out, bias, wsum, in_scale,
                      in_zero_point, w_scale, g, x_is_unsigned ? 128 : 0, ep, ConvSeg2{});
   return launch_status();
@@ -677,6 +707,31 @@ extern "C" int dlmcq_x_conv2d_i8_tuned(const void* x, const int8_t* w, float* ou
     g.pdiv = make_fastdiv((uint32_t)P);
     return dlmcq_conv_pp_launch(reinterpret_cast<const int8_t*>(x), w, out, bias, wsum, in_scale, in_zero_point, w_scale, g,
                                 x_is_unsigned ? 128 : 0, ep, nullptr, bn, pp_nbuf, pp_wps, reinterpret_cast<hipStream_t>(stream));
+  }
+  if (pp_wps < 0) {   // what-bounds-the-step variants of the 128-wide direct-A kernel (LAB = -pp_wps)
+    const int64_t P = (H + 2 * pad - dilation * (R - 1) - 1) / stride + 1, Q = (W + 2 * pad - dilation * (S - 1) - 1) / stride + 1;
+    if (C % CV_BK || K % 128 || P < 1 || Q < 1 || N * P * Q >= (1ll << 31)) return DLMCQ_EINVAL;
+    ConvGeom g;
+    g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C = (int)C; g.K = (int)K; g.R = (int)R; g.S = (int)S;
+    g.stride = stride; g.pad = pad; g.dil = dilation; g.P = (int)P; g.Q = (int)Q; g.M = N * P * Q;
+    g.qdiv = make_fastdiv((uint32_t)Q);
+    g.pdiv = make_fastdiv((uint32_t)P);
+    g.nblk_m = (int)((g.M + CV_BM - 1) / CV_BM);
+    g.nblk_n = (int)(K / 128);
+    const dim3 grid((uint32_t)((int64_t)g.nblk_m * g.nblk_n));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int8_t* xx = reinterpret_cast<const int8_t*>(x);
+    const int shift = x_is_unsigned ? 128 : 0;
+#define DLMCQ_LABK(V) hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, false, V>), grid, dim3(256), 0, st, xx, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, ConvSeg2{})
+    switch (-pp_wps) {
+      case 2: DLMCQ_LABK(2); break;
+      case 3: DLMCQ_LABK(3); break;
+      case 4: DLMCQ_LABK(4); break;
+      case 5: DLMCQ_LABK(5); break;
+      default: return DLMCQ_EINVAL;
+    }
+#undef DLMCQ_LABK
+    return launch_status();
   }
   const ConvPlan plan{bn, adir != 0};
   return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,

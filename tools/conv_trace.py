@@ -25,13 +25,15 @@ s_w = torch.full((k,), 0.002, device=dev)
 one = torch.full((1,), 0.02, device=dev)
 zp = torch.zeros(1, device=dev)
 codes = torch.empty(n, k, h, h, device=dev, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
-trace = torch.zeros(24 * 8, dtype=torch.int64, device=dev)
+nwg = ((n * h * h + 127) // 128) * (k // 128)
+trace = torch.zeros(24 * 8 + 6 * nwg, dtype=torch.int64, device=dev)
 for _ in range(3):
     rc = fn(N.ptr(x), N.ptr(wq), None, None, N.ptr(wsum), N.ptr(one), N.ptr(zp), N.ptr(s_w), n, h, h, c, k, r, r, 1, r // 2, 1, 1,
             N.ptr(codes), N.ptr(one), N.stream_ptr(), N.ptr(trace))
     assert rc == 0, rc
 torch.cuda.synchronize()
-t = trace.cpu().reshape(24, 8)
+wg = trace[24 * 8:].cpu().reshape(nwg, 6)
+t = trace[:24 * 8].cpu().reshape(24, 8)
 names = ["wait operands", "barrier", "issue next loads", "fragments + MFMAs"]
 print("step  " + "  ".join(f"{s:>18s}" for s in names) + "   whole step")
 tot = [0] * 4
@@ -46,3 +48,33 @@ for i in range(24):
         tot = [a + b for a, b in zip(tot, d)]
         cnt += 1
 print("mean  " + "  ".join(f"{v / max(cnt, 1):18.0f}" for v in tot))
+
+# whole-grid timeline.  Shader clocks are comparable within one XCD only: everything is relative to the XCD's first start.
+xcc = (wg[:, 5] & 15)
+se = (wg[:, 4] >> 13) & 7
+cu = (wg[:, 4] >> 8) & 15
+print(f"\n{nwg} workgroups; blockIdx & 7 == XCC_ID for {int(((torch.arange(nwg) & 7) == xcc).sum())} of them")
+for x in range(8):
+    sel = xcc == x
+    w = wg[sel]
+    if len(w) == 0:
+        continue
+    t0 = int(w[:, 0].min())
+    st, lp, le, en = [(w[:, j] - t0).float() for j in range(4)]
+    life = en - st
+    q = st.sort().values
+    qs = [int(q[int(f * (len(q) - 1))]) for f in (0, 0.25, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0)]
+    ncu = len(set((int(a), int(b)) for a, b in zip(se[sel], cu[sel])))
+    print(f"xcc {x}: {len(w)} WGs on {ncu} CUs, span {int(en.max())} clk; starts at 0/25/50/60/70/80/90/100 %: {qs}; "
+          f"life mean {life.mean():.0f} (min {life.min():.0f} max {life.max():.0f}); prologue {float((lp - st).mean()):.0f} "
+          f"K loop {float((le - lp).mean()):.0f} epilogue {float((en - le).mean()):.0f}")
+sel = xcc == 0
+w = wg[sel]
+idx = torch.nonzero(sel).flatten()
+t0 = int(w[:, 0].min())
+order = w[:, 0].argsort()
+print("xcc 0, every 6th workgroup by start time: blockIdx se.cu start | prologue, K loop, epilogue | end")
+for i in order[::6]:
+    i = int(i)
+    print(f"  wg {int(idx[i]):5d} {int(se[sel][i])}.{int(cu[sel][i]):<2d} start {int(w[i, 0]) - t0:8d} | {int(w[i, 1] - w[i, 0]):6d} {int(w[i, 2] - w[i, 1]):7d} "
+          f"{int(w[i, 3] - w[i, 2]):6d} | end {int(w[i, 3]) - t0:8d}")
