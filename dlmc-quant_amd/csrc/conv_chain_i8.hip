@@ -1,0 +1,329 @@
+// A residual block's LAST 1x1 convolution (+ shortcut + ReLU + the consumer's quantiser) and the NEXT block's FIRST 1x1
+// convolution (+ ReLU + its consumer's quantiser) as ONE kernel.  (FSPTQuant/base.py:95-159 twice, with the `out += identity;
+// relu` of the model between them; same arithmetic, same order as conv_i8.hip's kernel run twice: bit-identical.)
+//
+// Why: the block-end layer is an HBM stream (4 B shortcut in + 4 B fp32 out per element for a 64..256-deep reduction, MFMA
+// 3-5 % busy) and the activation codes it writes are read back exactly once, by the 1x1 reduction that follows, whose own
+// time is all operand traffic.  Here a workgroup owns <= 64 pixels for ALL K_d output channels of the block end, walks
+// them in chunks of 64 channels, and feeds each finished chunk of codes - still in LDS - to the second reduction as one K
+// step.  The wide code tensor is never read (and, inside a stage, never written); the second layer's MFMA work runs in
+// the shadow of the first layer's shortcut stream.
+//
+// Structure (256 threads = 2 x 2 waves: wave (wr, wc) owns rows wr*32.. and the column half wc):
+//   * A (the block-end input, <= 64 rows x C1 <= 256 B) is loaded ONCE into registers as MFMA fragments;
+//   * per chunk n: W1[n] (64 x C1), W3[:, n] (KB x 64) and the chunk's per-channel constants arrive by LDS-DMA into a
+//     double buffer, the chunk's shortcut tile by asm buffer loads into registers - all requested one chunk ahead; one
+//     counted s_waitcnt + one barrier, GEMM 1 (C1/32 MFMAs), epilogue 1 in registers (dequantise, 4x4 DPP transpose
+//     from the accumulator layout to rows of 4 consecutive channels, + shortcut, ReLU, 16-byte buffer stores, quantise),
+//     codes -> LDS, barrier, GEMM 2 step (KB/32 MFMAs into the resident second accumulator);
+//   * buffer instructions with the row guard folded into the offset (out-of-range lanes are dropped by the hardware), so
+//     every wave issues the same number of vector-memory instructions and the vmcnt arithmetic is exact.
+#include "conv_i8_common.h"
+
+namespace dlmcq {
+
+struct ChainArgs {
+  // GEMM 1: block end.  x codes [M][C1], w1 [KD][C1] int8, per-channel scale / code sum / bias [KD]
+  const int8_t* x;
+  const int8_t* w1;
+  const float* s_w1;
+  const int32_t* wsum1;
+  const float* bias1;
+  const float* s_in1;
+  const float* zp_in1;
+  int shift1;
+  const float* residual;   // fp32 [M][KD] (required)
+  float* out;              // fp32 [M][KD] or null
+  uint8_t* codes;          // [M][KD] or null
+  // GEMM 2: the next 1x1 reduction.  w3 [KB][KD] int8; its input quantiser is ep1's (scale, zero point)
+  const int8_t* w3;
+  const float* s_w3;
+  const int32_t* wsum3;
+  const float* bias3;
+  uint8_t* codes2;         // [M][KB]
+  int M, KD, rows_per_tile;
+};
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4i make_rsrc(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  return v4i{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void bload16(f32x4& dst, int voff, const v4i& rsrc) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void bstore16(const f32x4& v, int voff, const v4i& rsrc) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 0" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void bstore4(uint32_t v, int voff, const v4i& rsrc) {
+  asm volatile("buffer_store_dword %0, %1, %2, 0 offen nt" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// 4 x 4 transpose across the four lanes of a quad: afterwards x_j of lane b is what x_b of lane j was
+__device__ __forceinline__ void quad_transpose(float& x0, float& x1, float& x2, float& x3, bool b0, bool b1) {
+  const float x0s = quad_dpp<0xB1>(x0), x1s = quad_dpp<0xB1>(x1), x2s = quad_dpp<0xB1>(x2), x3s = quad_dpp<0xB1>(x3);
+  const float n0 = b0 ? x1s : x0, n1 = b0 ? x1 : x0s, n2 = b0 ? x3s : x2, n3 = b0 ? x3 : x2s;
+  const float n0s = quad_dpp<0x4E>(n0), n1s = quad_dpp<0x4E>(n1), n2s = quad_dpp<0x4E>(n2), n3s = quad_dpp<0x4E>(n3);
+  x0 = b1 ? n2s : n0;
+  x2 = b1 ? n2 : n0s;
+  x1 = b1 ? n3s : n1;
+  x3 = b1 ? n3 : n1s;
+}
+
+// workgroups per CU the kernel is compiled for (registers), by instantiation
+constexpr int CHAIN_WGS(int c1, int kb) { return 2; }
+constexpr int CH_BIG = 0x7fff0000;   // a byte offset beyond every buffer this kernel accepts (< 2^31 - 64 KiB)
+
+template <int C1, int KB>
+__global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(ChainArgs a, ConvEpi ep1, ConvEpi ep2) {
+  constexpr int S1 = C1 / 64;            // K steps of GEMM 1
+  constexpr int U3 = KB / 64;            // 64-row units of a W3 chunk = accumulator slabs of GEMM 2 per wave (KB/2 columns)
+  constexpr int WCH = (S1 + U3) * 4096;  // bytes of one chunk's weights
+  constexpr int PAR = 4 * 256;           // per-channel constants of one chunk (scale, code sum, bias, spare) x 64 columns
+  __shared__ __attribute__((aligned(1024))) int8_t lds[2 * WCH + 2 * PAR + 4096];
+  int8_t* const par0 = lds + 2 * WCH;
+  int8_t* const ctile = lds + 2 * WCH + 2 * PAR;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int q4 = l31 >> 2, b4 = l31 & 3;
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+  const int64_t row0 = (int64_t)blockIdx.x * a.rows_per_tile;
+  const int rows_here = (int)((a.M - row0) < a.rows_per_tile ? (a.M - row0) : a.rows_per_tile);
+  const int NC = a.KD >> 6;
+
+  // ---- A fragments of the whole tile row block (rows beyond the tile read its last row: never stored) ----
+  i32x4 af[S1][2];
+  {
+    const int lr = wr * 32 + l31;
+    const int8_t* xp = a.x + (row0 + (lr < rows_here ? lr : rows_here - 1)) * C1 + hsel * 16;
+    const uint32_t xw = a.shift1 ? 0x80808080u : 0u;
+#pragma unroll
+    for (int s = 0; s < S1; ++s)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const i32x4 t = *reinterpret_cast<const i32x4*>(xp + s * 64 + ks * 32);
+        af[s][ks] = i32x4{(int)(t.x ^ xw), (int)(t.y ^ xw), (int)(t.z ^ xw), (int)(t.w ^ xw)};
+      }
+  }
+  // make sure no compiler-known load is outstanding from here on (the counted waits below assume it)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- addressing of the fp32 tile in the transposed (row-major) layout: group g -> row wr*32 + 8g + 4 hsel + b4 ----
+  const uint32_t fbytes = (uint32_t)((int64_t)a.M * a.KD * 4);
+  const v4i r_res = make_rsrc(a.residual, fbytes);
+  const v4i r_out = make_rsrc(a.out ? (const void*)a.out : (const void*)a.residual, a.out ? fbytes : 0u);
+  const v4i r_cod = make_rsrc(a.codes ? (const void*)a.codes : (const void*)a.residual, a.codes ? fbytes / 4 : 0u);
+  int fo[4];     // byte offset of this lane's 16 bytes in chunk 0, per group (CH_BIG: row not in the tile)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int lr = wr * 32 + 8 * g + 4 * hsel + b4;
+    fo[g] = lr < rows_here ? (int)(((row0 + lr) * a.KD + wc * 32 + q4 * 4) * 4) : CH_BIG;
+  }
+  const int nst = (a.out ? 4 : 0) + (a.codes ? 4 : 0);   // stores per wave per chunk
+
+  // ---- DMA sources.  A wave-instruction lands 16 rows x 64 B; row r of a unit keeps its 16-byte segments XOR-swizzled ----
+  const int lrow = lane >> 2, pslot = lane & 3;
+  const int drow = wave * 16 + lrow;                       // row of a 64-row unit this lane fetches
+  const int dseg = (pslot ^ ((drow >> 2) & 3)) * 16;
+  const int8_t* w1p = a.w1 + (int64_t)drow * C1 + dseg;    // + chunk * 64 * C1 + s * 64
+  const int8_t* w3p = a.w3 + (int64_t)drow * a.KD + dseg;  // + unit * 64 * KD + chunk * 64
+  const void* const pars[4] = {a.s_w1, a.wsum1, a.bias1 ? (const void*)a.bias1 : (const void*)a.s_w1, a.s_w1};
+  const int32_t* parp = static_cast<const int32_t*>(wave == 0 ? pars[0] : wave == 1 ? pars[1] : wave == 2 ? pars[2] : pars[3]) + lane;
+
+  f32x4 res[2][4];
+  auto request = [&](int n, auto par_c) {    // everything chunk n needs from memory
+    constexpr int P = decltype(par_c)::value;
+    int8_t* wb = lds + P * WCH;
+#pragma unroll
+    for (int s = 0; s < S1; ++s)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w1p + (int64_t)n * 64 * C1 + s * 64), (lptr_t)(wb + s * 4096 + wave * 1024), 16, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U3; ++u)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w3p + (int64_t)u * 64 * a.KD + n * 64), (lptr_t)(wb + (S1 + u) * 4096 + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(parp + n * 64), (lptr_t)(par0 + P * PAR + wave * 256), 4, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bload16(res[P][g], fo[g] + n * 256, r_res);
+  };
+
+  const float sin1 = a.s_in1[0];
+  const float zpf1 = a.zp_in1 ? a.zp_in1[0] : 0.0f;
+  const int dz1 = a.shift1 - (int)__builtin_rintf(zpf1);
+  ConvEpi e1 = ep1;
+  e1.codes = reinterpret_cast<uint8_t*>(uintptr_t(1));   // the quantiser is always needed (GEMM 2 reads its codes)
+  const EpiQuant eq1(e1);
+
+  i32x16 acc2[U3];
+#pragma unroll
+  for (int j = 0; j < U3; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[j][i] = 0;
+
+  request(0, std::integral_constant<int, 0>{});
+
+  auto chunk = [&](int n, auto par_c) {
+    constexpr int P = decltype(par_c)::value;
+    // chunk n's requests have landed; the stores of chunk n-1 (younger) stay in flight
+    if (n == 0 || nst == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // everyone's DMA pieces are visible; everyone left GEMM 2 of chunk n-1
+    asm volatile("" : "+v"(res[P][0]), "+v"(res[P][1]), "+v"(res[P][2]), "+v"(res[P][3]));
+    if (n + 1 < NC) request(n + 1, std::integral_constant<int, 1 - P>{});
+
+    // ---- GEMM 1: rows wr*32.., columns n*64 + wc*32.. ----
+    const int8_t* wb = lds + P * WCH;
+    i32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    {
+      const int r = wc * 32 + l31;
+#pragma unroll
+      for (int s = 0; s < S1; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const i32x4 bf = *reinterpret_cast<const i32x4*>(wb + s * 4096 + r * 64 + (((ks * 2 + hsel) ^ ((r >> 2) & 3)) << 4));
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s][ks], bf, acc, 0, 0, 0);
+        }
+    }
+    // ---- epilogue 1 ----
+    const int8_t* pp = par0 + P * PAR + (wc * 32 + l31) * 4;
+    const float mult = sin1 * *reinterpret_cast<const float*>(pp);
+    const int corr = dz1 * *reinterpret_cast<const int*>(pp + 256);
+    const float bv = a.bias1 ? *reinterpret_cast<const float*>(pp + 512) : 0.0f;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (float)(acc[i] + corr) * mult + bv;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
+      f32x4 y = f32x4{v[4 * g] + res[P][g].x, v[4 * g + 1] + res[P][g].y, v[4 * g + 2] + res[P][g].z, v[4 * g + 3] + res[P][g].w};
+      if (ep1.relu) y = f32x4{relu_nan(y.x), relu_nan(y.y), relu_nan(y.z), relu_nan(y.w)};
+      const int off = fo[g] + n * 256;
+      if (a.out) bstore16(y, off, r_out);
+      const uint32_t c = eq1.code4(y);
+      if (a.codes) bstore4(c, fo[g] == CH_BIG ? CH_BIG : (off >> 2), r_cod);
+      const int R = wr * 32 + 8 * g + 4 * hsel + b4;
+      *reinterpret_cast<uint32_t*>(ctile + R * 64 + (((wc * 2 + (q4 >> 2)) ^ ((R >> 2) & 3)) << 4) + (q4 & 3) * 4) = c;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // the 64 x 64 code tile is complete
+    // ---- GEMM 2: one K step (this chunk's 64 channels) into the resident accumulator ----
+    {
+      const int R = wr * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const i32x4 t = *reinterpret_cast<const i32x4*>(ctile + R * 64 + (((ks * 2 + hsel) ^ ((R >> 2) & 3)) << 4));
+        const i32x4 a2 = i32x4{(int)(t.x ^ 0x80808080u), (int)(t.y ^ 0x80808080u), (int)(t.z ^ 0x80808080u), (int)(t.w ^ 0x80808080u)};
+#pragma unroll
+        for (int j = 0; j < U3; ++j) {
+          const int kb = wc * (KB / 2) + j * 32 + l31;
+          const i32x4 bf = *reinterpret_cast<const i32x4*>(wb + S1 * 4096 + kb * 64 + (((ks * 2 + hsel) ^ ((kb >> 2) & 3)) << 4));
+          acc2[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, bf, acc2[j], 0, 0, 0);
+        }
+      }
+    }
+  };
+  for (int n = 0; n < NC; n += 2) {
+    chunk(n, std::integral_constant<int, 0>{});
+    if (n + 1 < NC) chunk(n + 1, std::integral_constant<int, 1>{});
+  }
+
+  // ---- epilogue 2: the reduction layer's own dequantise, ReLU, its consumer's quantiser; codes only ----
+  const float sin2 = ep1.q_scale[0];                       // its input scale IS the quantiser the codes were made with
+  const float zpf2 = ep1.q_zp ? ep1.q_zp[0] : 0.0f;
+  const int dz2 = 128 - (int)__builtin_rintf(zpf2);
+  const EpiQuant eq2(ep2);
+#pragma unroll
+  for (int j = 0; j < U3; ++j) {
+    const int kb = wc * (KB / 2) + j * 32 + l31;
+    const float mult = sin2 * a.s_w3[kb];
+    const int corr = dz2 * a.wsum3[kb];
+    const float bv = a.bias3 ? a.bias3[kb] : 0.0f;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (float)(acc2[j][i] + corr) * mult + bv;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
+      f32x4 y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      if (ep2.relu) y = f32x4{relu_nan(y.x), relu_nan(y.y), relu_nan(y.z), relu_nan(y.w)};
+      const int lr = wr * 32 + 8 * g + 4 * hsel + b4;
+      if (lr < rows_here)
+        *reinterpret_cast<uint32_t*>(ep2.codes + (row0 + lr) * KB + wc * (KB / 2) + j * 32 + q4 * 4) = eq2.code4(y);
+    }
+  }
+}
+
+}  // namespace dlmcq
+
+using namespace dlmcq;
+
+// rows per workgroup: <= 64, chosen so that the last round of workgroups (4 or 2 resident per CU) is as full as possible
+static int chain_rows_per_tile(int64_t M, int wg_per_cu) {
+  const int64_t slots = 256ll * wg_per_cu;
+  int best = 64;
+  int64_t best_time = INT64_MAX;
+  for (int rows = 64; rows >= 40; --rows) {
+    const int64_t tiles = (M + rows - 1) / rows;
+    const int64_t rounds = (tiles + slots - 1) / slots;
+    const int64_t time = rounds * rows;     // every round streams `rows` rows per workgroup
+    if (time < best_time) {
+      best_time = time;
+      best = rows;
+    }
+  }
+  return best;
+}
+
+extern "C" int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                                          const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t M,
+                                          int64_t C, int64_t K, int32_t x_is_unsigned, const float* residual, int32_t relu,
+                                          void* codes, const float* q_scale, const float* q_zero_point, int32_t q_lo,
+                                          int32_t q_hi, int32_t q_form, float q_ste_g, const int8_t* w2, const float* bias2,
+                                          const int32_t* wsum2, const float* w_scale2, int64_t K2, int32_t relu2, void* codes2,
+                                          const float* q2_scale, const float* q2_zero_point, int32_t q2_lo, int32_t q2_hi,
+                                          int32_t q2_form, float q2_ste_g, int32_t rows_per_tile, dlmcq_stream_t stream) {
+  if (M < 0 || C < 1 || K < 1 || K2 < 1) return DLMCQ_EINVAL;
+  if (!((C == 64 && (K2 == 64 || K2 == 128)) || (C == 128 && (K2 == 128 || K2 == 256)) || (C == 256 && K2 == 256)) || K % 64 != 0)
+    return DLMCQ_EINVAL;
+  if (M == 0) return DLMCQ_OK;
+  if (!x || !w || !wsum || !in_scale || !w_scale || !residual || !w2 || !wsum2 || !w_scale2 || !codes2 || !q_scale || !q2_scale)
+    return DLMCQ_EINVAL;
+  if (q_lo != 0 || q_hi != 255) return DLMCQ_EINVAL;   // GEMM 2 reads the codes as uint8 (shift 128)
+  if (q2_lo > q2_hi || q2_lo < -128 || q2_hi > 255 || q2_hi - q2_lo > 255 || q_form < DLMCQ_FORM_EMULATE ||
+      q_form > DLMCQ_FORM_SYMMETRIC || q2_form < DLMCQ_FORM_EMULATE || q2_form > DLMCQ_FORM_SYMMETRIC)
+    return DLMCQ_EINVAL;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(w2) || !aligned16(residual) || (out && !aligned16(out)) ||
+      (codes && !aligned4(codes)) || !aligned4(codes2))
+    return DLMCQ_EALIGN;
+  if (M * K * 4 > (int64_t)CH_BIG) return DLMCQ_ERANGE;   // 32-bit buffer offsets
+  ChainArgs a{};
+  a.x = static_cast<const int8_t*>(x); a.w1 = w; a.s_w1 = w_scale; a.wsum1 = wsum; a.bias1 = bias;
+  a.s_in1 = in_scale; a.zp_in1 = in_zero_point; a.shift1 = x_is_unsigned ? 128 : 0;
+  a.residual = residual; a.out = out; a.codes = static_cast<uint8_t*>(codes);
+  a.w3 = w2; a.s_w3 = w_scale2; a.wsum3 = wsum2; a.bias3 = bias2; a.codes2 = static_cast<uint8_t*>(codes2);
+  a.M = (int)M; a.KD = (int)K;
+  const int wg_per_cu = CHAIN_WGS((int)C, (int)K2);
+  a.rows_per_tile = rows_per_tile > 0 ? rows_per_tile : chain_rows_per_tile(M, wg_per_cu);
+  if (a.rows_per_tile < 1 || a.rows_per_tile > 64) return DLMCQ_EINVAL;
+  ConvEpi ep1{}, ep2{};
+  ep1.relu = relu != 0; ep1.q_scale = q_scale; ep1.q_zp = q_zero_point; ep1.q_lo = (float)q_lo; ep1.q_hi = (float)q_hi;
+  ep1.q_g = q_ste_g; ep1.q_form = q_form; ep1.codes = static_cast<uint8_t*>(codes);
+  ep2.relu = relu2 != 0; ep2.q_scale = q2_scale; ep2.q_zp = q2_zero_point; ep2.q_lo = (float)q2_lo; ep2.q_hi = (float)q2_hi;
+  ep2.q_g = q2_ste_g; ep2.q_form = q2_form; ep2.codes = static_cast<uint8_t*>(codes2);
+  const int64_t tiles = (M + a.rows_per_tile - 1) / a.rows_per_tile;
+  if (tiles >= (1ll << 31)) return DLMCQ_ERANGE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((uint32_t)tiles), block(256);
+  if (C == 64 && K2 == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 64>), grid, block, 0, st, a, ep1, ep2);
+  else if (C == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 128>), grid, block, 0, st, a, ep1, ep2);
+  else if (C == 128 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 128>), grid, block, 0, st, a, ep1, ep2);
+  else if (C == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 256>), grid, block, 0, st, a, ep1, ep2);
+  else hipLaunchKernelGGL((conv_chain_i8_kernel<256, 256>), grid, block, 0, st, a, ep1, ep2);
+  return launch_status();
+}

@@ -540,6 +540,60 @@ def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True):
     return (out, out_codes) if emit is not None else out
 
 
+CHAIN_SHAPES = {(64, 64), (64, 128), (128, 128), (128, 256), (256, 256)}   # (C, K2) pairs dlmcq_conv2d_i8_nhwc_chain is built for
+
+
+def chain_supported(c, k, k2, m):
+    """Whether dlmcq_conv2d_i8_nhwc_chain takes a block end [m, c] -> [m, k] followed by a reduction to k2."""
+    return (c, k2) in CHAIN_SHAPES and k % 64 == 0 and m * k * 4 <= 0x7fff0000
+
+
+def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_codes=False, relu2=True, emit2=None,
+                    rows_per_tile=0):
+    """A block's last 1x1 convolution (+ residual, ReLU, the consumer's quantiser `emit`) and the next block's first 1x1
+    convolution (+ ReLU, its consumer's quantiser `emit2`) in one kernel (dlmcq_conv2d_i8_nhwc_chain).  `a`: dict with
+    codes, wq, wsum, bias, in_scale, in_zp, w_scale of the first layer; `b`: wq, wsum, bias, w_scale of the second (its
+    input quantiser is `emit`).  Returns (out or None, codes or None, codes2)."""
+    c = a["codes"]
+    N.require_gpu(c, a["wq"], b["wq"], residual)
+    if not c.is_contiguous(memory_format=torch.channels_last):
+        c = c.contiguous(memory_format=torch.channels_last)
+    n, ch, h, w_ = c.shape
+    K_, R, S, _ = a["wq"].shape
+    K2, R2, S2, C2 = b["wq"].shape
+    if (R, S, R2, S2) != (1, 1, 1, 1) or C2 != K_ or emit is None or emit2 is None:
+        raise ValueError("conv2d_i8_chain: two 1x1 convolutions, the second reading the first's codes")
+    if tuple(residual.shape) != (n, K_, h, w_) or residual.dtype != torch.float32:
+        raise ValueError("conv2d_i8_chain: residual must be fp32 of the first output's shape")
+    if not residual.is_contiguous(memory_format=torch.channels_last):
+        residual = residual.contiguous(memory_format=torch.channels_last)
+    m = n * h * w_
+
+    def alloc(k, dtype):
+        return torch.empty((n, k, h, w_), dtype=dtype, device=c.device, memory_format=torch.channels_last)
+    out = alloc(K_, torch.float32) if want_out else None
+    codes = alloc(K_, emit.dtype) if want_codes else None
+    codes2 = alloc(K2, emit2.dtype)
+
+    def vec(t, k):
+        t = _f32c(t.detach(), c).reshape(-1)
+        return t.expand(k).contiguous() if t.numel() == 1 else t
+    ws1, ws2 = vec(a["w_scale"], K_), vec(b["w_scale"], K2)
+    si = _f32c(a["in_scale"].detach(), c).reshape(-1)
+    zp = None if a["in_zp"] is None else _f32c(a["in_zp"], c).reshape(-1)
+    b1 = None if a["bias"] is None else a["bias"].detach().contiguous()
+    b2 = None if b["bias"] is None else b["bias"].detach().contiguous()
+    qs, qz = _f32c(emit.scale.detach(), c).reshape(-1), None if emit.zero_point is None else _f32c(emit.zero_point, c).reshape(-1)
+    qs2, qz2 = _f32c(emit2.scale.detach(), c).reshape(-1), None if emit2.zero_point is None else _f32c(emit2.zero_point, c).reshape(-1)
+    nbytes = c.numel() + a["wq"].numel() + b["wq"].numel() + m * K_ * (4 + 4 * want_out + want_codes) + m * K2
+    PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_chain(
+        N.ptr(c), N.ptr(a["wq"]), N.ptr(out), N.ptr(b1), N.ptr(a["wsum"]), N.ptr(si), N.ptr(zp), N.ptr(ws1), m, ch, K_,
+        int(c.dtype == torch.uint8), N.ptr(residual), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi,
+        emit.form, emit.g, N.ptr(b["wq"]), N.ptr(b2), N.ptr(b["wsum"]), N.ptr(ws2), K2, int(bool(relu2)), N.ptr(codes2),
+        N.ptr(qs2), N.ptr(qz2), emit2.lo, emit2.hi, emit2.form, emit2.g, int(rows_per_tile), N.stream_ptr())))
+    return out, codes, codes2
+
+
 def quantize_pad_nhwc4(x, scale, zero_point, lo, hi, form, pad, g=0.0):
     """Image batch (N, C <= 4, H, W) fp32, any memory format -> activation codes in a zero-point-padded NHWC
     buffer, 4 bytes per pixel: uint8/int8 tensor (N, H + 2 pad, W + 2 pad, 4) (a view of a slightly larger

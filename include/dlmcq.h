@@ -378,6 +378,29 @@ int dlmcq_conv2d_i8_nhwc_dual(const void* x, const int8_t* w, float* out, const 
                               const float* q_zero_point, int32_t q_lo, int32_t q_hi, int32_t q_form,
                               float q_ste_g, dlmcq_stream_t stream);
 
+/*
+ * A residual block's LAST 1x1 convolution and the NEXT block's FIRST 1x1 convolution as one kernel
+ * (csrc/conv_chain_i8.hip):
+ *     v      = conv1x1(x, w) + bias + residual;  ReLU (if relu);  out = v (optional);  codes = Q(v) (optional)
+ *     codes2 = Q2( ReLU?( conv1x1( Q(v), w2 ) + bias2 ) )
+ * i.e. dlmcq_conv2d_i8_nhwc_fused on [M, C] -> [M, K] (stride 1, no padding) followed by the same call on its `codes`
+ * with [K2, K] weights, `relu2` and the second consumer's quantiser Q2 - bit-identical to those two calls - but the
+ * [M, K] code tensor stays in LDS: it is not read back, and not written unless `codes` is given.  M = N*H*W pixels;
+ * x: [M][C] codes; w: [K][C]; residual (required) / out: fp32 [M][K]; w2: [K2][K]; codes2: [M][K2].
+ * Q must be an unsigned 8-bit quantiser (q_lo = 0, q_hi = 255: the second reduction reads uint8 codes).
+ * Supported: (C, K2) in {(64,64), (64,128), (128,128), (128,256), (256,256)}, K % 64 == 0, M*K*4 < 2^31 - 64 Ki
+ * (anything else: DLMCQ_EINVAL / DLMCQ_ERANGE; callers fall back to the two separate calls).
+ * rows_per_tile: pixels per workgroup, 1..64; <= 0 picks the value that fills the last round of workgroups best.
+ */
+int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                               const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t M,
+                               int64_t C, int64_t K, int32_t x_is_unsigned, const float* residual, int32_t relu,
+                               void* codes, const float* q_scale, const float* q_zero_point, int32_t q_lo,
+                               int32_t q_hi, int32_t q_form, float q_ste_g, const int8_t* w2, const float* bias2,
+                               const int32_t* wsum2, const float* w_scale2, int64_t K2, int32_t relu2, void* codes2,
+                               const float* q2_scale, const float* q2_zero_point, int32_t q2_lo, int32_t q2_hi,
+                               int32_t q2_form, float q2_ste_g, int32_t rows_per_tile, dlmcq_stream_t stream);
+
 /* ---- the 3-channel first layer and its max-pool, in the integer-code domain (csrc/conv_stem_i8.hip) ---- */
 
 /*

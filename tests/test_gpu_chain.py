@@ -1,0 +1,67 @@
+"""dlmcq_conv2d_i8_nhwc_chain (block end + next block's 1x1 reduction in one kernel) against the two separate
+dlmcq_conv2d_i8_nhwc_fused calls it replaces: fp32 output, intermediate codes and final codes bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(n, h, c, k, k2, seed, zp1=3.0, zp2=0.0):
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randint(0, 256, (n, c, h, h), generator=g, device=dev, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+    w1 = torch.randint(-127, 128, (k, 1, 1, c), generator=g, device=dev, dtype=torch.int8)
+    w2 = torch.randint(-127, 128, (k2, 1, 1, k), generator=g, device=dev, dtype=torch.int8)
+    a = dict(codes=x, wq=w1, wsum=w1.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous(),
+             bias=torch.randn(k, generator=g, device=dev), in_scale=torch.full((1,), 0.02, device=dev),
+             in_zp=torch.full((1,), zp1, device=dev), w_scale=(torch.rand(k, generator=g, device=dev) * 0.004 + 0.001))
+    b = dict(wq=w2, wsum=w2.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous(),
+             bias=torch.randn(k2, generator=g, device=dev), w_scale=(torch.rand(k2, generator=g, device=dev) * 0.002 + 0.0005))
+    res = (torch.randn(n, k, h, h, generator=g, device=dev) * 2).contiguous(memory_format=torch.channels_last)
+    emit = K.EmitCodes(torch.full((1,), 0.05, device=dev), torch.full((1,), zp2, device=dev), 0, 255, N.FORM_ZEROPOINT)
+    emit2 = K.EmitCodes(torch.full((1,), 0.11, device=dev), torch.zeros(1, device=dev), 0, 255, N.FORM_ZEROPOINT)
+    return K, a, b, res, emit, emit2
+
+
+def _reference(K, a, b, res, emit, emit2):
+    out, codes = K.conv2d_i8(a["codes"], a["wq"], a["wsum"], a["bias"], a["in_scale"], a["in_zp"], a["w_scale"], residual=res,
+                             relu=True, emit=emit, want_out=True)
+    _, codes2 = K.conv2d_i8(codes, b["wq"], b["wsum"], b["bias"], emit.scale, emit.zero_point, b["w_scale"], relu=True, emit=emit2,
+                            want_out=False)
+    return out, codes, codes2
+
+
+@pytest.mark.parametrize("c,k,k2", [(64, 256, 64), (64, 256, 128), (128, 512, 128), (128, 512, 256), (256, 1024, 256)])
+@pytest.mark.parametrize("rows", [0, 64, 49])
+def test_chain_matches_two_calls(c, k, k2, rows):
+    n, h = 3, 14                      # 588 pixels: partial last tile for every tile height
+    K, a, b, res, emit, emit2 = _case(n, h, c, k, k2, seed=c + k2 + rows)
+    out_r, codes_r, codes2_r = _reference(K, a, b, res, emit, emit2)
+    for want_out, want_codes in ((True, False), (False, True), (True, True)):
+        out, codes, codes2 = K.conv2d_i8_chain(a, b, res, relu=True, emit=emit, want_out=want_out, want_codes=want_codes,
+                                               relu2=True, emit2=emit2, rows_per_tile=rows)
+        torch.cuda.synchronize()
+        if want_out:
+            assert torch.equal(out.view(torch.int32), out_r.view(torch.int32))
+        if want_codes:
+            assert torch.equal(codes, codes_r)
+        assert torch.equal(codes2, codes2_r)
+
+
+def test_chain_larger_batch_and_nonzero_zero_points():
+    K, a, b, res, emit, emit2 = _case(64, 28, 128, 512, 128, seed=7, zp1=0.0, zp2=5.0)
+    out_r, codes_r, codes2_r = _reference(K, a, b, res, emit, emit2)
+    out, codes, codes2 = K.conv2d_i8_chain(a, b, res, emit=emit, want_out=True, want_codes=True, emit2=emit2)
+    assert torch.equal(out.view(torch.int32), out_r.view(torch.int32))
+    assert torch.equal(codes, codes_r) and torch.equal(codes2, codes2_r)
+
+
+def test_chain_refuses_unsupported_shapes():
+    K, a, b, res, emit, emit2 = _case(1, 7, 64, 256, 64, seed=1)
+    assert K.chain_supported(64, 256, 64, 49) and not K.chain_supported(512, 2048, 512, 49)
+    bad = dict(b, wq=torch.zeros(96, 1, 1, 256, dtype=torch.int8, device="cuda:0"), wsum=torch.zeros(96, dtype=torch.int32, device="cuda:0"),
+               bias=torch.zeros(96, device="cuda:0"), w_scale=torch.ones(96, device="cuda:0"))
+    with pytest.raises(RuntimeError):
+        K.conv2d_i8_chain(a, bad, res, emit=emit, emit2=emit2)
