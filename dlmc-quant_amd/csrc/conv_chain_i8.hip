@@ -42,6 +42,8 @@ struct ChainArgs {
   const float* bias3;
   uint8_t* codes2;         // [M][KB]
   int M, KD, rows_per_tile;
+  int lab;                     // lab builds: 1 = no shortcut loads (timing only)
+  unsigned long long* trace;   // lab builds: 64 clock-stamp slots per workgroup (null: none)
 };
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -53,8 +55,11 @@ __device__ __forceinline__ v4i make_rsrc(const void* p, uint32_t bytes) {
 __device__ __forceinline__ void bload16(f32x4& dst, int voff, const v4i& rsrc) {
   asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
 }
+// (a store of more than 8 bytes reads its data registers late: gfx940+ needs TWO wait states before a VALU instruction may
+//  overwrite them, and the hazard recogniser does not see inside inline asm - with one, the last quad of every 16 lanes
+//  can store the NEXT value of a dword)
 __device__ __forceinline__ void bstore16(const f32x4& v, int voff, const v4i& rsrc) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 0" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void bstore4(uint32_t v, int voff, const v4i& rsrc) {
   asm volatile("buffer_store_dword %0, %1, %2, 0 offen nt" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
@@ -75,7 +80,7 @@ __device__ __forceinline__ void quad_transpose(float& x0, float& x1, float& x2, 
 }
 
 // workgroups per CU the kernel is compiled for (registers), by instantiation
-constexpr int CHAIN_WGS(int c1, int kb) { return 2; }
+constexpr int CHAIN_WGS(int c1, int kb) { return c1 + kb <= 256 ? 3 : 2; }
 constexpr int CH_BIG = 0x7fff0000;   // a byte offset beyond every buffer this kernel accepts (< 2^31 - 64 KiB)
 
 template <int C1, int KB>
@@ -95,6 +100,14 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
   const int64_t row0 = (int64_t)blockIdx.x * a.rows_per_tile;
   const int rows_here = (int)((a.M - row0) < a.rows_per_tile ? (a.M - row0) : a.rows_per_tile);
   const int NC = a.KD >> 6;
+#ifdef DLMCQ_LAB
+  unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + 64 * (size_t)blockIdx.x : nullptr;
+  int trn = 0;
+#define CHAIN_STAMP() do { if (tr && trn < 56) tr[trn++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CHAIN_STAMP() do { } while (0)
+#endif
+  CHAIN_STAMP();   // 0: start
 
   // ---- A fragments of the whole tile row block (rows beyond the tile read its last row: never stored) ----
   i32x4 af[S1][2];
@@ -112,6 +125,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
   }
   // make sure no compiler-known load is outstanding from here on (the counted waits below assume it)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CHAIN_STAMP();   // 1: A fragments in registers
 
   // ---- addressing of the fp32 tile in the transposed (row-major) layout: group g -> row wr*32 + 8g + 4 hsel + b4 ----
   const uint32_t fbytes = (uint32_t)((int64_t)a.M * a.KD * 4);
@@ -136,6 +150,11 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
   const int32_t* parp = static_cast<const int32_t*>(wave == 0 ? pars[0] : wave == 1 ? pars[1] : wave == 2 ? pars[2] : pars[3]) + lane;
 
   f32x4 res[2][4];
+#ifdef DLMCQ_LAB
+  if (a.lab & 1)
+    for (auto& r2 : res)
+      for (auto& r : r2) r = f32x4{1.0f, 2.0f, 3.0f, 4.0f};
+#endif
   auto request = [&](int n, auto par_c) {    // everything chunk n needs from memory
     constexpr int P = decltype(par_c)::value;
     int8_t* wb = lds + P * WCH;
@@ -147,7 +166,12 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
       __builtin_amdgcn_global_load_lds((gptr_t)(w3p + (int64_t)u * 64 * a.KD + n * 64), (lptr_t)(wb + (S1 + u) * 4096 + wave * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(parp + n * 64), (lptr_t)(par0 + P * PAR + wave * 256), 4, 0, 0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bload16(res[P][g], fo[g] + n * 256, r_res);
+    for (int g = 0; g < 4; ++g) {
+#ifdef DLMCQ_LAB
+      if (a.lab & 1) continue;
+#endif
+      bload16(res[P][g], fo[g] + n * 256, r_res);
+    }
   };
 
   const float sin1 = a.s_in1[0];
@@ -172,6 +196,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
     else if (nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // everyone's DMA pieces are visible; everyone left GEMM 2 of chunk n-1
+    CHAIN_STAMP();   // 2 + 3n: chunk n's operands are there
     asm volatile("" : "+v"(res[P][0]), "+v"(res[P][1]), "+v"(res[P][2]), "+v"(res[P][3]));
     if (n + 1 < NC) request(n + 1, std::integral_constant<int, 1 - P>{});
 
@@ -197,7 +222,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
     const float bv = a.bias1 ? *reinterpret_cast<const float*>(pp + 512) : 0.0f;
     float v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = (float)(acc[i] + corr) * mult + bv;
+    for (int i = 0; i < 16; ++i) v[i] = dequant1(acc[i] + corr, mult, bv);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
@@ -210,8 +235,10 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
       const int R = wr * 32 + 8 * g + 4 * hsel + b4;
       *reinterpret_cast<uint32_t*>(ctile + R * 64 + (((wc * 2 + (q4 >> 2)) ^ ((R >> 2) & 3)) << 4) + (q4 & 3) * 4) = c;
     }
+    CHAIN_STAMP();   // 3 + 3n: GEMM 1 + epilogue 1 issued
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // the 64 x 64 code tile is complete
+    CHAIN_STAMP();   // 4 + 3n: past the mid-chunk barrier
     // ---- GEMM 2: one K step (this chunk's 64 channels) into the resident accumulator ----
     {
       const int R = wr * 32 + l31;
@@ -233,6 +260,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
     if (n + 1 < NC) chunk(n + 1, std::integral_constant<int, 1>{});
   }
 
+  CHAIN_STAMP();   // chunks done
   // ---- epilogue 2: the reduction layer's own dequantise, ReLU, its consumer's quantiser; codes only ----
   const float sin2 = ep1.q_scale[0];                       // its input scale IS the quantiser the codes were made with
   const float zpf2 = ep1.q_zp ? ep1.q_zp[0] : 0.0f;
@@ -246,7 +274,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
     const float bv = a.bias3 ? a.bias3[kb] : 0.0f;
     float v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = (float)(acc2[j][i] + corr) * mult + bv;
+    for (int i = 0; i < 16; ++i) v[i] = dequant1(acc2[j][i] + corr, mult, bv);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
@@ -257,28 +285,25 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
         *reinterpret_cast<uint32_t*>(ep2.codes + (row0 + lr) * KB + wc * (KB / 2) + j * 32 + q4 * 4) = eq2.code4(y);
     }
   }
+#ifdef DLMCQ_LAB
+  if (tr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CHAIN_STAMP();   // end
+    tr[63] = __builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_ID
+  }
+#endif
 }
 
 }  // namespace dlmcq
 
 using namespace dlmcq;
 
-// rows per workgroup: <= 64, chosen so that the last round of workgroups (4 or 2 resident per CU) is as full as possible
-static int chain_rows_per_tile(int64_t M, int wg_per_cu) {
-  const int64_t slots = 256ll * wg_per_cu;
-  int best = 64;
-  int64_t best_time = INT64_MAX;
-  for (int rows = 64; rows >= 40; --rows) {
-    const int64_t tiles = (M + rows - 1) / rows;
-    const int64_t rounds = (tiles + slots - 1) / slots;
-    const int64_t time = rounds * rows;     // every round streams `rows` rows per workgroup
-    if (time < best_time) {
-      best_time = time;
-      best = rows;
-    }
-  }
-  return best;
-}
+#ifdef DLMCQ_LAB
+static unsigned long long* g_chain_trace = nullptr;   // set by dlmcq_x_chain_trace (tools/chain_trace.py)
+extern "C" void dlmcq_x_chain_trace(void* buf) { g_chain_trace = static_cast<unsigned long long*>(buf); }
+static int g_chain_lab = 0;
+extern "C" void dlmcq_x_chain_lab(int flags) { g_chain_lab = flags; }
+#endif
 
 extern "C" int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
                                           const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t M,
@@ -308,9 +333,12 @@ extern "C" int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float*
   a.residual = residual; a.out = out; a.codes = static_cast<uint8_t*>(codes);
   a.w3 = w2; a.s_w3 = w_scale2; a.wsum3 = wsum2; a.bias3 = bias2; a.codes2 = static_cast<uint8_t*>(codes2);
   a.M = (int)M; a.KD = (int)K;
-  const int wg_per_cu = CHAIN_WGS((int)C, (int)K2);
-  a.rows_per_tile = rows_per_tile > 0 ? rows_per_tile : chain_rows_per_tile(M, wg_per_cu);
-  if (a.rows_per_tile < 1 || a.rows_per_tile > 64) return DLMCQ_EINVAL;
+#ifdef DLMCQ_LAB
+  a.trace = g_chain_trace;
+  a.lab = g_chain_lab;
+#endif
+  a.rows_per_tile = rows_per_tile > 0 ? rows_per_tile : 64;   // (tile heights that fill the last round of workgroups exactly - 56, 49 - measured slower)
+  if (a.rows_per_tile > 64) return DLMCQ_EINVAL;
   ConvEpi ep1{}, ep2{};
   ep1.relu = relu != 0; ep1.q_scale = q_scale; ep1.q_zp = q_zero_point; ep1.q_lo = (float)q_lo; ep1.q_hi = (float)q_hi;
   ep1.q_g = q_ste_g; ep1.q_form = q_form; ep1.codes = static_cast<uint8_t*>(codes);

@@ -25,12 +25,42 @@ struct ConvEpi {
   int relu;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The one rounding chain of every int8 kernel: exact integer sum -> fp32, then ONE fused multiply-add with the layer's
+// (s_in * s_w[k]) and bias[k].  (Rounds 1-2a multiplied and added separately; fused is one VALU instruction fewer per element
+// in epilogues that are bound by exactly that, and one rounding closer to the real-valued result.)
+__device__ __forceinline__ float dequant1(int sum, float mult, float bias) { return __builtin_fmaf((float)sum, mult, bias); }
+
+// torch.relu on four values (relu_nan: NaN and -0 pass) as 4 compares into 4 different SGPR pairs followed by 4 selects: the
+// compiler's rendering serialises on vcc with wait states after every compare
+__device__ __forceinline__ f32x4 relu4_nan(const f32x4& y) {
+  float o0, o1, o2, o3;
+  uint64_t m0, m1, m2, m3;
+  asm("v_cmp_ngt_f32_e64 %[m0], 0, %[y0]\n\t"
+      "v_cmp_ngt_f32_e64 %[m1], 0, %[y1]\n\t"
+      "v_cmp_ngt_f32_e64 %[m2], 0, %[y2]\n\t"
+      "v_cmp_ngt_f32_e64 %[m3], 0, %[y3]\n\t"
+      "v_cndmask_b32_e64 %[o0], 0, %[y0], %[m0]\n\t"
+      "v_cndmask_b32_e64 %[o1], 0, %[y1], %[m1]\n\t"
+      "v_cndmask_b32_e64 %[o2], 0, %[y2], %[m2]\n\t"
+      "v_cndmask_b32_e64 %[o3], 0, %[y3], %[m3]"
+      : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2),
+        [m3] "=&s"(m3)
+      : [y0] "v"(y.x), [y1] "v"(y.y), [y2] "v"(y.z), [y3] "v"(y.w));
+  return f32x4{o0, o1, o2, o3};
+}
+
 struct EpiQuant {   // the consumer's constants, resolved once per thread
   float dv, rdv, of, zadd, lo, hi;
+  float lo_fast;    // lower clamp of the fast path: `lo`, or max(lo, code of 0) when the ReLU is folded into the quantiser
   int form;
-  bool sgn;
-  __device__ __forceinline__ EpiQuant(const ConvEpi& ep)
-      : dv(1.0f), rdv(1.0f), of(0.0f), zadd(0.0f), lo(ep.q_lo), hi(ep.q_hi), form(ep.q_form), sgn(ep.q_lo < 0.0f) {
+  bool sgn, fold;
+  // fold_relu: the caller quantises relu(v) but passes v: every form is monotone, so code(relu(v)) = max(code(v), code(0))
+  // for a finite v - one clamp bound instead of a compare + select per element (NaN takes the exact path, which rectifies)
+  __device__ __forceinline__ EpiQuant(const ConvEpi& ep, bool fold_relu = false)
+      : dv(1.0f), rdv(1.0f), of(0.0f), zadd(0.0f), lo(ep.q_lo), hi(ep.q_hi), lo_fast(ep.q_lo), form(ep.q_form),
+        sgn(ep.q_lo < 0.0f), fold(fold_relu) {
     if (!ep.codes) return;
     const float s = ep.q_scale[0];
     const float z = ep.q_zp ? ep.q_zp[0] : 0.0f;
@@ -40,19 +70,34 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
     zadd = form == DLMCQ_FORM_ZEROPOINT ? z : 0.0f;
     // the fast path below is proven for a well-scaled divisor and a byte-sized zero point; anything else (and NaN)
     // makes rdv NaN, which routes every element to the exact division
-    const bool tame = __builtin_fabsf(dv) >= 0x1p-100f && __builtin_fabsf(dv) <= 0x1p100f && __builtin_fabsf(zadd) <= 256.0f;
+    const bool tame = __builtin_fabsf(dv) >= 0x1p-100f && __builtin_fabsf(dv) <= 0x1p100f && __builtin_fabsf(zadd) <= 256.0f &&
+                      zadd == __builtin_rintf(zadd);
     rdv = tame ? 1.0f / dv : __builtin_nanf("");
+    if (fold) {
+      const float q0 = exact_q(0.0f);
+      lo_fast = q0 > lo ? q0 : lo;     // (a NaN code of 0 - NaN scale - keeps lo; rdv is NaN then and nothing takes the fast path)
+    }
   }
   // the reference arithmetic itself, form by form (fq_one): what the fast path below must reproduce, and what decides
   // the elements it cannot vouch for.  (Not interchangeable with the reduced formula for +-inf: the STE identity
   // R(v) = (rint(v) - v) + v turns an infinite quotient into NaN -> code 0, where EMULATE's plain rint saturates.)
-  __device__ __forceinline__ uint32_t exact(float v) const {
-    float q;
-    if (form == DLMCQ_FORM_EMULATE) q = clamp_nan(__builtin_rintf((v - of) / dv), lo, hi);
-    else if (form == DLMCQ_FORM_QBASE) q = ste_round(clamp_nan((v - of) / dv, lo, hi));
-    else if (form == DLMCQ_FORM_ZEROPOINT) q = clamp_nan(ste_round(v / dv) + zadd, lo, hi);
-    else q = clamp_nan(ste_round(v / dv), lo, hi);
-    return (uint32_t)(code_of(q) & 0xff);
+  __device__ __forceinline__ float exact_q(float v) const {
+    if (form == DLMCQ_FORM_EMULATE) return clamp_nan(__builtin_rintf((v - of) / dv), lo, hi);
+    if (form == DLMCQ_FORM_QBASE) return ste_round(clamp_nan((v - of) / dv, lo, hi));
+    if (form == DLMCQ_FORM_ZEROPOINT) return clamp_nan(ste_round(v / dv) + zadd, lo, hi);
+    return clamp_nan(ste_round(v / dv), lo, hi);
+  }
+  __device__ __forceinline__ uint32_t exact(float v) const { return (uint32_t)(code_of(exact_q(v)) & 0xff); }
+  // four of them, as a loop (one copy of the division per call site: the kernels inline code4 many times)
+  __device__ __forceinline__ uint32_t exact4(const f32x4& v) const {
+    uint32_t w = 0;
+#pragma unroll 1
+    for (int e = 0; e < 4; ++e) {
+      float u = e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
+      if (fold) u = relu_nan(u);
+      w |= exact(u) << (8 * e);
+    }
+    return w;
   }
   // For a FINITE quotient d = fl(u / dv), u = v - of, all four forms reduce to  code = clamp(rint(d) + zadd, lo, hi)
   // (rint(clamp(d)) = clamp(rint(d)) for integral bounds; the STE identity (r - d) + d returns r exactly).
@@ -60,17 +105,28 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
   // so d is replaced by t = fl(u * fl(1/dv)), which differs from d by less than 2^-22 |t|.  For |t| <= 512 that is
   // below 2^-13: unless t lies within 2^-12 of a rounding tie (x.5), rint(t) = rint(d); for |t| > 512 both saturate
   // to the same bound (|zadd| <= 256, |lo|, |hi| <= 255).  Ties that close, infinities and NaNs (about one element in
-  // 2000) take the exact division, four elements at a time.  Bit-identical codes at ~10 operations per element.
-  __device__ __forceinline__ uint32_t code4(const f32x4& v) const {
-    const float t0 = (v.x - of) * rdv, t1 = (v.y - of) * rdv, t2 = (v.z - of) * rdv, t3 = (v.w - of) * rdv;
+  // 2000) take the exact division, four elements at a time.  Bit-identical codes at ~6 operations per element: the
+  // block-end layers are bound by the VALU instructions of their epilogue (tools/chain_trace.py), so the arithmetic
+  // is written on pairs (v_pk_add_f32 / v_pk_mul_f32: two elements per instruction, same roundings), and a non-finite
+  // t needs no separate test: t - rint(t) is NaN then, and NaN is "not below the threshold".
+  // the fast path alone, branch-free: the packed codes and whether any of the four needs the exact division instead.
+  // Callers with several independent quads evaluate them all, OR the flags and branch ONCE: a branch per quad chains
+  // the quads one behind the other (each ~25 dependent instructions long), which is what bounded the block-end layers.
+  // The zero point rides on the multiply: t = fma(u, 1/dv, zadd) (zadd is integral, checked above), q = rint(t).  t differs
+  // from u/dv + zadd by less than 2^-22 |u/dv| + 2^-24 |t| < 2^-12 in the range that does not saturate, so the argument above
+  // carries over with the tie test applied to t itself: 6 instructions per element (fma, rint, sub, compare, clamp, pack)
+  // when the form has no offset to subtract first (OFZ).
+  template <bool OFZ>
+  __device__ __forceinline__ uint32_t code4_fast(const f32x4& v, bool& unsure) const {
+    const float u0 = OFZ ? v.x : v.x - of, u1 = OFZ ? v.y : v.y - of, u2 = OFZ ? v.z : v.z - of, u3 = OFZ ? v.w : v.w - of;
+    const float t0 = __builtin_fmaf(u0, rdv, zadd), t1 = __builtin_fmaf(u1, rdv, zadd), t2 = __builtin_fmaf(u2, rdv, zadd),
+                t3 = __builtin_fmaf(u3, rdv, zadd);
     const float r0 = __builtin_rintf(t0), r1 = __builtin_rintf(t1), r2 = __builtin_rintf(t2), r3 = __builtin_rintf(t3);
-    // worst distance from an integer; a non-finite input poisons it through (sum * 0), max() alone would drop a NaN
-    float worst = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t0 - r0), __builtin_fabsf(t1 - r1)),
-                                  __builtin_fmaxf(__builtin_fabsf(t2 - r2), __builtin_fabsf(t3 - r3)));
-    worst = worst + ((t0 + t1) + (t2 + t3)) * 0.0f;
-    if (!(worst < 0.5f - 0x1p-12f)) return exact(v.x) | (exact(v.y) << 8) | (exact(v.z) << 16) | (exact(v.w) << 24);
-    float q0 = __builtin_amdgcn_fmed3f(r0 + zadd, lo, hi), q1 = __builtin_amdgcn_fmed3f(r1 + zadd, lo, hi);
-    float q2 = __builtin_amdgcn_fmed3f(r2 + zadd, lo, hi), q3 = __builtin_amdgcn_fmed3f(r3 + zadd, lo, hi);
+    constexpr float thr = 0.5f - 0x1p-12f;
+    unsure = !(__builtin_fabsf(t0 - r0) < thr) | !(__builtin_fabsf(t1 - r1) < thr) | !(__builtin_fabsf(t2 - r2) < thr) |
+             !(__builtin_fabsf(t3 - r3) < thr);
+    float q0 = __builtin_amdgcn_fmed3f(r0, lo_fast, hi), q1 = __builtin_amdgcn_fmed3f(r1, lo_fast, hi);
+    float q2 = __builtin_amdgcn_fmed3f(r2, lo_fast, hi), q3 = __builtin_amdgcn_fmed3f(r3, lo_fast, hi);
     if (sgn) {   // two's-complement byte of a negative code
       q0 = q0 < 0.0f ? q0 + 256.0f : q0;
       q1 = q1 < 0.0f ? q1 + 256.0f : q1;
@@ -81,6 +137,36 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
     w = __builtin_amdgcn_cvt_pk_u8_f32(q1, 1, w);
     w = __builtin_amdgcn_cvt_pk_u8_f32(q2, 2, w);
     return __builtin_amdgcn_cvt_pk_u8_f32(q3, 3, w);
+  }
+  __device__ __forceinline__ uint32_t code4(const f32x4& v) const {
+    bool unsure;
+    const uint32_t w = code4_fast<false>(v, unsure);
+    return unsure ? exact4(v) : w;
+  }
+  // N independent quads: one branch for all of them
+  // `u` (optional) receives the per-quad flags, for callers that have more to redo on the exact path (a NaN's ReLU)
+  template <int N>
+  __device__ __forceinline__ bool code4n(const f32x4 (&v)[N], uint32_t (&w)[N], bool (&u)[N]) const {
+    bool any = false;
+    if (of == 0.0f) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        w[i] = code4_fast<true>(v[i], u[i]);
+        any |= u[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        w[i] = code4_fast<false>(v[i], u[i]);
+        any |= u[i];
+      }
+    }
+    if (any) {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (u[i]) w[i] = exact4(v[i]);
+    }
+    return any;
   }
 };
 

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
         const float bv2 = sg.bias ? par_f(5, j) : 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          extra[DUAL ? j : 0][i] = (float)(acc[j][i] + corr) * mult + bv2;
+          extra[DUAL ? j : 0][i] = dequant1(acc[j][i] + corr, mult, bv2);
           acc[j][i] = 0;
         }
       }
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int r = (i & 3) + 8 * (i >> 2) + 4 * hsel;
-          float v = (float)(acc[j][i] + corr[j]) * mult[j] + p_bias[j];
+          float v = dequant1(acc[j][i] + corr[j], mult[j], p_bias[j]);
           if (DUAL) v = v + extra[DUAL ? j : 0][i];
           if (ASYM) v = v + s0r[ASYM ? i : 0] * woff[ASYM ? j : 0];
           stg[r * EP_LD + jj * 32 + l31] = v;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
       const int64_t row = m0 + wrow0 + (i & 3) + 8 * (i >> 2) + 4 * hsel;
       if (row >= g.M) continue;
       const int64_t at = row * g.K + col;
-      float v = (float)(acc[j][i] + corr[j]) * mult[j] + p_bias[j];
+      float v = dequant1(acc[j][i] + corr[j], mult[j], p_bias[j]);
       if (DUAL) v = v + extra[DUAL ? j : 0][i];
       if (ASYM) v = v + s0r[ASYM ? i : 0] * woff[ASYM ? j : 0];
       if (ep.residual) v = v + ep.residual[at];

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, WPS) void conv_i8_pp_kernel(const int8_t* __re
           const float bv = has_bias2 ? A1<ATOP - 1 - (A1_PAR + 5 * NT + j)>::read_f() : 0.0f;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            extra[DUAL ? j : 0][i] = (float)(acc[j][i] + corr) * mult + bv;
+            extra[DUAL ? j : 0][i] = dequant1(acc[j][i] + corr, mult, bv);
             acc[j][i] = 0;
           }
         });
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, WPS) void conv_i8_pp_kernel(const int8_t* __re
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int r = (i & 3) + 8 * (i >> 2) + 4 * hsel;
-          float v = (float)(acc[j][i] + corr[j]) * mult[j] + bv[j];
+          float v = dequant1(acc[j][i] + corr[j], mult[j], bv[j]);
           if (DUAL) v = v + extra[DUAL ? j : 0][i];
           stg[r * EP_LD + jj * 32 + l31] = v;
           acc[j][i] = 0;
