@@ -61,8 +61,8 @@ __device__ __forceinline__ void bload16(f32x4& dst, int voff, const v4i& rsrc) {
 __device__ __forceinline__ void bstore16(const f32x4& v, int voff, const v4i& rsrc) {
   asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
-__device__ __forceinline__ void bstore4(uint32_t v, int voff, const v4i& rsrc) {
-  asm volatile("buffer_store_dword %0, %1, %2, 0 offen nt" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+__device__ __forceinline__ void bstore16i(const i32x4& v, int voff, const v4i& rsrc) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
 template <int CTRL>
 __device__ __forceinline__ float quad_dpp(float v) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
     const int lr = wr * 32 + 8 * g + 4 * hsel + b4;
     fo[g] = lr < rows_here ? (int)(((row0 + lr) * a.KD + wc * 32 + q4 * 4) * 4) : CH_BIG;
   }
-  const int nst = (a.out ? 4 : 0) + (a.codes ? 4 : 0);   // stores per wave per chunk
+  const int nst = (a.out ? 4 : 0) + (a.codes ? 1 : 0);   // stores per wave per chunk
 
   // ---- DMA sources.  A wave-instruction lands 16 rows x 64 B; row r of a unit keeps its 16-byte segments XOR-swizzled ----
   const int lrow = lane >> 2, pslot = lane & 3;
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
   const int dseg = (pslot ^ ((drow >> 2) & 3)) * 16;
   const int8_t* w1p = a.w1 + (int64_t)drow * C1 + dseg;    // + chunk * 64 * C1 + s * 64
   const int8_t* w3p = a.w3 + (int64_t)drow * a.KD + dseg;  // + unit * 64 * KD + chunk * 64
+  const int cvo = drow < rows_here ? (int)((row0 + drow) * a.KD + dseg) : CH_BIG;   // this lane's 16 bytes of the code tile, chunk 0
   const void* const pars[4] = {a.s_w1, a.wsum1, a.bias1 ? (const void*)a.bias1 : (const void*)a.s_w1, a.s_w1};
   const int32_t* parp = static_cast<const int32_t*>(wave == 0 ? pars[0] : wave == 1 ? pars[1] : wave == 2 ? pars[2] : pars[3]) + lane;
 
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
     // chunk n's requests have landed; the stores of chunk n-1 (younger) stay in flight
     if (n == 0 || nst == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nst == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // everyone's DMA pieces are visible; everyone left GEMM 2 of chunk n-1
     CHAIN_STAMP();   // 2 + 3n: chunk n's operands are there
     asm volatile("" : "+v"(res[P][0]), "+v"(res[P][1]), "+v"(res[P][2]), "+v"(res[P][3]));
@@ -231,7 +233,6 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
       const int off = fo[g] + n * 256;
       if (a.out) bstore16(y, off, r_out);
       const uint32_t c = eq1.code4(y);
-      if (a.codes) bstore4(c, fo[g] == CH_BIG ? CH_BIG : (off >> 2), r_cod);
       const int R = wr * 32 + 8 * g + 4 * hsel + b4;
       *reinterpret_cast<uint32_t*>(ctile + R * 64 + (((wc * 2 + (q4 >> 2)) ^ ((R >> 2) & 3)) << 4) + (q4 & 3) * 4) = c;
     }
@@ -239,6 +240,8 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // the 64 x 64 code tile is complete
     CHAIN_STAMP();   // 4 + 3n: past the mid-chunk barrier
+    if (a.codes)     // stage ends: the tile goes out 64 contiguous bytes per pixel (slot s of row r holds segment s ^ (r >> 2 & 3))
+      bstore16i(*reinterpret_cast<const i32x4*>(ctile + drow * 64 + pslot * 16), cvo == CH_BIG ? CH_BIG : cvo + n * 64, r_cod);
     // ---- GEMM 2: one K step (this chunk's 64 channels) into the resident accumulator ----
     {
       const int R = wr * 32 + l31;
@@ -324,7 +327,7 @@ extern "C" int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float*
       q_form > DLMCQ_FORM_SYMMETRIC || q2_form < DLMCQ_FORM_EMULATE || q2_form > DLMCQ_FORM_SYMMETRIC)
     return DLMCQ_EINVAL;
   if (!aligned16(x) || !aligned16(w) || !aligned16(w2) || !aligned16(residual) || (out && !aligned16(out)) ||
-      (codes && !aligned4(codes)) || !aligned4(codes2))
+      (codes && !aligned16(codes)) || !aligned4(codes2))
     return DLMCQ_EALIGN;
   if (M * K * 4 > (int64_t)CH_BIG) return DLMCQ_ERANGE;   // 32-bit buffer offsets
   ChainArgs a{};

@@ -357,6 +357,86 @@ class DualInt8Layer(nn.Module):
         return a._finish(out, out_codes)
 
 
+class ChainInt8Layer(nn.Module):
+    """A residual block's last 1x1 convolution (+ shortcut, ReLU) and the next block's first 1x1 convolution as ONE kernel
+    (csrc/conv_chain_i8.hip): the activation codes between them stay in LDS.  Returns `(fp32 or None, codes or None, codes2)`;
+    shapes the kernel is not built for run the two plan nodes one after the other."""
+
+    def __init__(self, a, b, want_codes):
+        super().__init__()
+        self.a, self.b, self.want_codes = a, b, bool(want_codes)
+
+    def forward(self, x, residual):
+        a, b = self.a, self.b
+        codes = a._codes(x)
+        n, c, h, w = codes.shape
+        if not K.chain_supported(c, a.k, b.k, n * h * w):
+            out, mid = a(x, residual)
+            return out, (mid if self.want_codes else None), b(mid)[1]
+        oa = dict(codes=codes, wq=a.wq, wsum=a.wsum, bias=a._bias(), in_scale=a._in_scale(a._real_numel(codes)), in_zp=a.act.zp,
+                  w_scale=a.w_scale)
+        ob = dict(wq=b.wq, wsum=b.wsum, bias=b._bias(), w_scale=b.w_scale)
+        return K.conv2d_i8_chain(oa, ob, residual, relu=a.relu, emit=a._emit_for(n, a.k, h, w), want_out=a.want_out,
+                                 want_codes=self.want_codes, relu2=b.relu, emit2=b._emit_for(n, b.k, h, w))
+
+
+def _pointwise(plan):
+    """A plan node the chain kernel can take as either half: a plain 1x1 / stride 1 / unpadded int8 convolution."""
+    lay = plan.layer
+    return (type(plan) is Int8Layer and lay.weight.dim() == 4 and tuple(lay.weight.shape[2:]) == (1, 1) and lay.stride[0] == 1 and
+            lay.padding[0] == 0 and plan.w_off is None and plan.pool is None and plan.k_pad == plan.k and plan.c_pad == plan.c and
+            not plan.act.needs_g)
+
+
+def _chain_pass(gm, report):
+    """Block end -> next block's first 1x1: replace the two plan nodes by one ChainInt8Layer where the second reads nothing
+    but the first's codes (other readers of those codes - a stage's downsample convolution - keep getting them)."""
+    graph = gm.graph
+    modules = dict(gm.named_modules())
+    count = 0
+    for na in list(graph.nodes):
+        if na.op != "call_module" or len(na.args) != 2 or not isinstance(modules.get(na.target), Int8Layer):
+            continue
+        a = modules[na.target]
+        if not (_pointwise(a) and a.emit is not None and (a.emit.lo, a.emit.hi) == (0, 255) and not a.emit.needs_g):
+            continue
+        gets = {u.args[1]: u for u in na.users if u.op == "call_function" and u.target is operator.getitem}
+        if len(gets) != len(na.users) or 1 not in gets:
+            continue
+        g1 = gets[1]
+        nb = next((u for u in g1.users if u.op == "call_module" and u.args == (g1,) and isinstance(modules.get(u.target), Int8Layer) and
+                   _pointwise(modules[u.target]) and modules[u.target].emit is not None and not modules[u.target].want_out and
+                   not modules[u.target].emit.needs_g and modules[u.target].c == a.k and
+                   (a.c, modules[u.target].k) in K.CHAIN_SHAPES), None)
+        if nb is None:
+            continue
+        b = modules[nb.target]
+        bgets = {u.args[1]: u for u in nb.users if u.op == "call_function" and u.target is operator.getitem}
+        if len(bgets) != len(nb.users) or (0 in bgets and bgets[0].users):
+            continue
+        name = f"_int8_chain_{count}"
+        count += 1
+        gm.add_module(name, ChainInt8Layer(a, b, want_codes=len(g1.users) > 1))
+        with graph.inserting_after(na):
+            nc = graph.call_module(name, args=na.args)
+        with graph.inserting_after(nc):
+            outs = [graph.call_function(operator.getitem, (nc, i)) for i in (2, 1, 0)][::-1]
+        if 0 in gets:
+            gets[0].replace_all_uses_with(outs[0])
+        for u in list(g1.users):
+            if u is not nb:
+                u.replace_input_with(g1, outs[1])
+        if 1 in bgets:
+            bgets[1].replace_all_uses_with(outs[2])
+        for n in list(bgets.values()) + [nb] + list(gets.values()) + [na]:
+            graph.erase_node(n)
+    report.chained = count
+    if count:
+        graph.eliminate_dead_code()
+        graph.lint()
+        gm.recompile()
+
+
 class StemLayer(_PlanLayer):
     """The network's first convolution (<= 4 input channels) of the frozen plan: the image is quantised into a
     zero-point-padded NHWC4 code buffer and convolved on the matrix cores (csrc/conv_stem_i8.hip)."""
@@ -391,12 +471,14 @@ class FusionReport:
 
     def __init__(self):
         self.layers = self.relu = self.residual = self.emit = self.fp32_outputs = self.stem = self.pooled = self.dual = 0
+        self.chained = 0      # block end + next block's 1x1 pairs running as one kernel
         self.skipped = []
 
     def __repr__(self):
         return (f"FusionReport(int8 layers={self.layers}, relu fused={self.relu}, residual fused={self.residual}, "
                 f"code-emitting={self.emit}, fp32 outputs kept={self.fp32_outputs}, stem layers={self.stem}, "
-                f"pools on codes={self.pooled}, dual (conv + shortcut conv) kernels={self.dual}, not eligible={self.skipped})")
+                f"pools on codes={self.pooled}, dual (conv + shortcut conv) kernels={self.dual}, chained pairs={self.chained}, "
+                f"not eligible={self.skipped})")
 
 
 class _Tracer(fx.Tracer):
@@ -438,11 +520,12 @@ def _pool_params(node, modules):
     return k, s, p
 
 
-def fuse_inference(model, report=None, dry_run=False):
+def fuse_inference(model, report=None, dry_run=False, chain_pairs=True):
     """Return a `torch.fx.GraphModule` executing `model`'s calibrated quantised forward as the fused int8 plan.
     Layers that are not eligible (grouped / 3-channel convs, non-integer zero points, RootQ, ...) keep running
     their own wrapper.  `model` must be on the GPU, in eval mode, already calibrated.  `dry_run=True` only takes the
-    fusion decisions (graph + `fusion_report`, placeholder nodes): it needs no GPU and the result cannot be run."""
+    fusion decisions (graph + `fusion_report`, placeholder nodes): it needs no GPU and the result cannot be run.
+    `chain_pairs=False` keeps every block end and the 1x1 convolution behind it as two launches (A/B and tests)."""
     if model.training:
         raise RuntimeError("fuse_inference: the plan is for inference - call model.eval() first")
     report = report if report is not None else FusionReport()
@@ -580,6 +663,8 @@ def fuse_inference(model, report=None, dry_run=False):
     graph.eliminate_dead_code()
     graph.lint()
     gm.recompile()
+    if chain_pairs and not dry_run:
+        _chain_pass(gm, report)
     gm.fusion_report = report
     return gm
 

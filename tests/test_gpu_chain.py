@@ -65,3 +65,38 @@ def test_chain_refuses_unsupported_shapes():
                bias=torch.zeros(96, device="cuda:0"), w_scale=torch.ones(96, device="cuda:0"))
     with pytest.raises(RuntimeError):
         K.conv2d_i8_chain(a, bad, res, emit=emit, emit2=emit2)
+
+
+def test_resnet50_plan_chains_the_block_boundaries_and_stays_bit_identical():
+    """The plan pass pairs every non-dual block end with the next block's first 1x1 (stage ends keep their codes for the
+    downsample convolution); logits equal the unchained plan's and the wrappers' bit for bit."""
+    import workloads as W
+    from dlmc.utils.fuse import ChainInt8Layer, fuse_inference
+    from dlmc.utils.merge_bn import merge_bn
+    from dlmc.utils.quantize import quantize_model
+    cfg = {"weight": {"enable": True, "type": "minmax_channel", "args": {"n_bits": 8, "signed": True}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+           "exclude_layers": [], "override_options": []}
+    torch.manual_seed(2333)
+    net = W.MODELS["resnet50"]().to("cuda:0").eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    net = merge_bn(net, inplace=True)
+    quantize_model(net, cfg, None, "FSPTQ", int8_gemm=True)
+    x = torch.relu(torch.randn(6, 3, 64, 64, device="cuda:0"))
+    with torch.no_grad():
+        net(x)                                  # calibrate
+        want = net(x * 0.8)
+        plain = fuse_inference(net, chain_pairs=False)
+        chained = fuse_inference(net)
+        rep = chained.fusion_report
+        # 16 blocks: 4 dual block ends (not chained yet), the very last one has no successor, the 1024 -> 512 stage end is
+        # wider than the kernel is built for, stage 4 altogether: 9 pairs, 2 of them stage ends that still write their codes
+        assert plain.fusion_report.chained == 0 and rep.chained == 9, rep
+        pairs = [m for m in chained.modules() if isinstance(m, ChainInt8Layer)]
+        assert len(pairs) == 9 and sum(m.want_codes for m in pairs) == 2
+        y0, y1 = plain(x * 0.8), chained(x * 0.8)
+    assert torch.equal(y0.view(torch.int32), y1.view(torch.int32))
+    assert torch.equal(y1.view(torch.int32), want.view(torch.int32))
