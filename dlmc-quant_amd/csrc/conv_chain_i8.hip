@@ -32,7 +32,18 @@ struct ChainArgs {
   const float* s_in1;
   const float* zp_in1;
   int shift1;
-  const float* residual;   // fp32 [M][KD] (required)
+  const float* residual;   // fp32 [M][KD] (required unless the shortcut is a convolution: C2 > 0)
+  // the shortcut as a second 1x1 convolution into the same tile (C2 > 0; the block's downsample): x2 codes [N][H2][W2][C2]
+  // sampled at (p * stride2, q * stride2), w2 [KD][C2]
+  const int8_t* x2;
+  const int8_t* w2;
+  const float* s_w2;
+  const int32_t* wsum2;
+  const float* bias2;
+  const float* s_in2;
+  const float* zp_in2;
+  int shift2, P, Q, H2, W2, stride2;
+  FastDiv qdiv, pdiv;
   float* out;              // fp32 [M][KD] or null
   uint8_t* codes;          // [M][KD] or null
   // GEMM 2: the next 1x1 reduction.  w3 [KB][KD] int8; its input quantiser is ep1's (scale, zero point)
@@ -83,12 +94,15 @@ __device__ __forceinline__ void quad_transpose(float& x0, float& x1, float& x2, 
 constexpr int CHAIN_WGS(int c1, int kb) { return c1 + kb <= 256 ? 3 : 2; }
 constexpr int CH_BIG = 0x7fff0000;   // a byte offset beyond every buffer this kernel accepts (< 2^31 - 64 KiB)
 
-template <int C1, int KB>
-__global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(ChainArgs a, ConvEpi ep1, ConvEpi ep2) {
+template <int C1, int KB, int C2 = 0>
+__global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_kernel(ChainArgs a, ConvEpi ep1, ConvEpi ep2) {
+  constexpr bool DUALH = C2 > 0;         // the shortcut is a second convolution (no fp32 shortcut tensor)
   constexpr int S1 = C1 / 64;            // K steps of GEMM 1
+  constexpr int S2 = C2 / 64;            // K steps of the shortcut convolution
   constexpr int U3 = KB / 64;            // 64-row units of a W3 chunk = accumulator slabs of GEMM 2 per wave (KB/2 columns)
-  constexpr int WCH = (S1 + U3) * 4096;  // bytes of one chunk's weights
-  constexpr int PAR = 4 * 256;           // per-channel constants of one chunk (scale, code sum, bias, spare) x 64 columns
+  constexpr int WCH = (S1 + S2 + U3) * 4096;  // bytes of one chunk's weights
+  constexpr int NPD = DUALH ? 2 : 1;     // constant-table DMAs per wave per chunk
+  constexpr int PAR = NPD * 4 * 256;     // per-channel constants of one chunk ((scale, code sum, bias) per pair) x 64 columns
   __shared__ __attribute__((aligned(1024))) int8_t lds[2 * WCH + 2 * PAR + 4096];
   int8_t* const par0 = lds + 2 * WCH;
   int8_t* const ctile = lds + 2 * WCH + 2 * PAR;
@@ -123,6 +137,22 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
         af[s][ks] = i32x4{(int)(t.x ^ xw), (int)(t.y ^ xw), (int)(t.z ^ xw), (int)(t.w ^ xw)};
       }
   }
+  i32x4 af2[DUALH ? S2 : 1][2];
+  if constexpr (DUALH) {
+    const int lr = wr * 32 + l31;
+    const uint32_t m = (uint32_t)(row0 + (lr < rows_here ? lr : rows_here - 1));
+    const uint32_t t = fdiv(m, a.qdiv), nn = fdiv(t, a.pdiv);
+    const int q = (int)(m - t * (uint32_t)a.Q), pp = (int)(t - nn * (uint32_t)a.P);
+    const int8_t* xp = a.x2 + (((int64_t)nn * a.H2 + pp * a.stride2) * a.W2 + q * a.stride2) * C2 + hsel * 16;
+    const uint32_t xw = a.shift2 ? 0x80808080u : 0u;
+#pragma unroll
+    for (int s = 0; s < S2; ++s)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const i32x4 t4 = *reinterpret_cast<const i32x4*>(xp + s * 64 + ks * 32);
+        af2[s][ks] = i32x4{(int)(t4.x ^ xw), (int)(t4.y ^ xw), (int)(t4.z ^ xw), (int)(t4.w ^ xw)};
+      }
+  }
   // make sure no compiler-known load is outstanding from here on (the counted waits below assume it)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   CHAIN_STAMP();   // 1: A fragments in registers
@@ -149,6 +179,9 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
   const int cvo = drow < rows_here ? (int)((row0 + drow) * a.KD + dseg) : CH_BIG;   // this lane's 16 bytes of the code tile, chunk 0
   const void* const pars[4] = {a.s_w1, a.wsum1, a.bias1 ? (const void*)a.bias1 : (const void*)a.s_w1, a.s_w1};
   const int32_t* parp = static_cast<const int32_t*>(wave == 0 ? pars[0] : wave == 1 ? pars[1] : wave == 2 ? pars[2] : pars[3]) + lane;
+  const int8_t* w2p = DUALH ? a.w2 + (int64_t)drow * C2 + dseg : nullptr;
+  const void* const pars2[4] = {a.s_w2, a.wsum2, a.bias2 ? (const void*)a.bias2 : (const void*)a.s_w2, a.s_w2};
+  const int32_t* parp2 = static_cast<const int32_t*>(wave == 0 ? pars2[0] : wave == 1 ? pars2[1] : wave == 2 ? pars2[2] : pars2[3]) + lane;
 
   f32x4 res[2][4];
 #ifdef DLMCQ_LAB
@@ -164,8 +197,15 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
       __builtin_amdgcn_global_load_lds((gptr_t)(w1p + (int64_t)n * 64 * C1 + s * 64), (lptr_t)(wb + s * 4096 + wave * 1024), 16, 0, 0);
 #pragma unroll
     for (int u = 0; u < U3; ++u)
-      __builtin_amdgcn_global_load_lds((gptr_t)(w3p + (int64_t)u * 64 * a.KD + n * 64), (lptr_t)(wb + (S1 + u) * 4096 + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w3p + (int64_t)u * 64 * a.KD + n * 64), (lptr_t)(wb + (S1 + S2 + u) * 4096 + wave * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(parp + n * 64), (lptr_t)(par0 + P * PAR + wave * 256), 4, 0, 0);
+    if constexpr (DUALH) {
+#pragma unroll
+      for (int s = 0; s < S2; ++s)
+        __builtin_amdgcn_global_load_lds((gptr_t)(w2p + (int64_t)n * 64 * C2 + s * 64), (lptr_t)(wb + (S1 + s) * 4096 + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(parp2 + n * 64), (lptr_t)(par0 + P * PAR + 1024 + wave * 256), 4, 0, 0);
+      return;      // no fp32 shortcut tile
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #ifdef DLMCQ_LAB
@@ -178,6 +218,8 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
   const float sin1 = a.s_in1[0];
   const float zpf1 = a.zp_in1 ? a.zp_in1[0] : 0.0f;
   const int dz1 = a.shift1 - (int)__builtin_rintf(zpf1);
+  const float sin1b = DUALH ? a.s_in2[0] : 0.0f;
+  const int dz1b = DUALH ? a.shift2 - (int)__builtin_rintf(a.zp_in2 ? a.zp_in2[0] : 0.0f) : 0;
   ConvEpi e1 = ep1;
   e1.codes = reinterpret_cast<uint8_t*>(uintptr_t(1));   // the quantiser is always needed (GEMM 2 reads its codes)
   const EpiQuant eq1(e1);
@@ -199,12 +241,31 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
     else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // everyone's DMA pieces are visible; everyone left GEMM 2 of chunk n-1
     CHAIN_STAMP();   // 2 + 3n: chunk n's operands are there
-    asm volatile("" : "+v"(res[P][0]), "+v"(res[P][1]), "+v"(res[P][2]), "+v"(res[P][3]));
+    if constexpr (!DUALH) asm volatile("" : "+v"(res[P][0]), "+v"(res[P][1]), "+v"(res[P][2]), "+v"(res[P][3]));
     if (n + 1 < NC) request(n + 1, std::integral_constant<int, 1 - P>{});
 
-    // ---- GEMM 1: rows wr*32.., columns n*64 + wc*32.. ----
     const int8_t* wb = lds + P * WCH;
+    const int8_t* pp = par0 + P * PAR + (wc * 32 + l31) * 4;
     i32x16 acc;
+    float extra[DUALH ? 16 : 1];
+    if constexpr (DUALH) {   // the shortcut convolution first: dequantised, it waits in registers for the block's own sum
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0;
+      const int r = wc * 32 + l31;
+#pragma unroll
+      for (int s = 0; s < S2; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const i32x4 bf = *reinterpret_cast<const i32x4*>(wb + (S1 + s) * 4096 + r * 64 + (((ks * 2 + hsel) ^ ((r >> 2) & 3)) << 4));
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af2[s][ks], bf, acc, 0, 0, 0);
+        }
+      const float mult2 = sin1b * *reinterpret_cast<const float*>(pp + 1024);
+      const int corr2 = dz1b * *reinterpret_cast<const int*>(pp + 1024 + 256);
+      const float bv2 = a.bias2 ? *reinterpret_cast<const float*>(pp + 1024 + 512) : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) extra[i] = dequant1(acc[i] + corr2, mult2, bv2);
+    }
+    // ---- GEMM 1: rows wr*32.., columns n*64 + wc*32.. ----
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0;
     {
@@ -218,17 +279,20 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
         }
     }
     // ---- epilogue 1 ----
-    const int8_t* pp = par0 + P * PAR + (wc * 32 + l31) * 4;
     const float mult = sin1 * *reinterpret_cast<const float*>(pp);
     const int corr = dz1 * *reinterpret_cast<const int*>(pp + 256);
     const float bv = a.bias1 ? *reinterpret_cast<const float*>(pp + 512) : 0.0f;
     float v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = dequant1(acc[i] + corr, mult, bv);
+    for (int i = 0; i < 16; ++i) {
+      v[i] = dequant1(acc[i] + corr, mult, bv);
+      if constexpr (DUALH) v[i] = v[i] + extra[DUALH ? i : 0];     // `out += identity`, the identity being a convolution
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
-      f32x4 y = f32x4{v[4 * g] + res[P][g].x, v[4 * g + 1] + res[P][g].y, v[4 * g + 2] + res[P][g].z, v[4 * g + 3] + res[P][g].w};
+      f32x4 y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      if constexpr (!DUALH) y = y + res[P][g];
       if (ep1.relu) y = f32x4{relu_nan(y.x), relu_nan(y.y), relu_nan(y.z), relu_nan(y.w)};
       const int off = fo[g] + n * 256;
       if (a.out) bstore16(y, off, r_out);
@@ -252,7 +316,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1, KB)) void conv_chain_i8_kernel(C
 #pragma unroll
         for (int j = 0; j < U3; ++j) {
           const int kb = wc * (KB / 2) + j * 32 + l31;
-          const i32x4 bf = *reinterpret_cast<const i32x4*>(wb + S1 * 4096 + kb * 64 + (((ks * 2 + hsel) ^ ((kb >> 2) & 3)) << 4));
+          const i32x4 bf = *reinterpret_cast<const i32x4*>(wb + (S1 + S2) * 4096 + kb * 64 + (((ks * 2 + hsel) ^ ((kb >> 2) & 3)) << 4));
           acc2[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, bf, acc2[j], 0, 0, 0);
         }
       }
@@ -308,33 +372,15 @@ static int g_chain_lab = 0;
 extern "C" void dlmcq_x_chain_lab(int flags) { g_chain_lab = flags; }
 #endif
 
-extern "C" int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
-                                          const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t M,
-                                          int64_t C, int64_t K, int32_t x_is_unsigned, const float* residual, int32_t relu,
-                                          void* codes, const float* q_scale, const float* q_zero_point, int32_t q_lo,
-                                          int32_t q_hi, int32_t q_form, float q_ste_g, const int8_t* w2, const float* bias2,
-                                          const int32_t* wsum2, const float* w_scale2, int64_t K2, int32_t relu2, void* codes2,
-                                          const float* q2_scale, const float* q2_zero_point, int32_t q2_lo, int32_t q2_hi,
-                                          int32_t q2_form, float q2_ste_g, int32_t rows_per_tile, dlmcq_stream_t stream) {
-  if (M < 0 || C < 1 || K < 1 || K2 < 1) return DLMCQ_EINVAL;
-  if (!((C == 64 && (K2 == 64 || K2 == 128)) || (C == 128 && (K2 == 128 || K2 == 256)) || (C == 256 && K2 == 256)) || K % 64 != 0)
-    return DLMCQ_EINVAL;
-  if (M == 0) return DLMCQ_OK;
-  if (!x || !w || !wsum || !in_scale || !w_scale || !residual || !w2 || !wsum2 || !w_scale2 || !codes2 || !q_scale || !q2_scale)
-    return DLMCQ_EINVAL;
+static int chain_launch(ChainArgs& a, int64_t M, int64_t C, int64_t K, int64_t C2, int64_t K2, int32_t relu, void* codes,
+                        const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi, int32_t q_form, float q_ste_g,
+                        int32_t relu2, void* codes2, const float* q2_scale, const float* q2_zero_point, int32_t q2_lo, int32_t q2_hi,
+                        int32_t q2_form, float q2_ste_g, int32_t rows_per_tile, dlmcq_stream_t stream) {
   if (q_lo != 0 || q_hi != 255) return DLMCQ_EINVAL;   // GEMM 2 reads the codes as uint8 (shift 128)
   if (q2_lo > q2_hi || q2_lo < -128 || q2_hi > 255 || q2_hi - q2_lo > 255 || q_form < DLMCQ_FORM_EMULATE ||
       q_form > DLMCQ_FORM_SYMMETRIC || q2_form < DLMCQ_FORM_EMULATE || q2_form > DLMCQ_FORM_SYMMETRIC)
     return DLMCQ_EINVAL;
-  if (!aligned16(x) || !aligned16(w) || !aligned16(w2) || !aligned16(residual) || (out && !aligned16(out)) ||
-      (codes && !aligned16(codes)) || !aligned4(codes2))
-    return DLMCQ_EALIGN;
   if (M * K * 4 > (int64_t)CH_BIG) return DLMCQ_ERANGE;   // 32-bit buffer offsets
-  ChainArgs a{};
-  a.x = static_cast<const int8_t*>(x); a.w1 = w; a.s_w1 = w_scale; a.wsum1 = wsum; a.bias1 = bias;
-  a.s_in1 = in_scale; a.zp_in1 = in_zero_point; a.shift1 = x_is_unsigned ? 128 : 0;
-  a.residual = residual; a.out = out; a.codes = static_cast<uint8_t*>(codes);
-  a.w3 = w2; a.s_w3 = w_scale2; a.wsum3 = wsum2; a.bias3 = bias2; a.codes2 = static_cast<uint8_t*>(codes2);
   a.M = (int)M; a.KD = (int)K;
 #ifdef DLMCQ_LAB
   a.trace = g_chain_trace;
@@ -351,10 +397,78 @@ extern "C" int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float*
   if (tiles >= (1ll << 31)) return DLMCQ_ERANGE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((uint32_t)tiles), block(256);
-  if (C == 64 && K2 == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 64>), grid, block, 0, st, a, ep1, ep2);
-  else if (C == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 128>), grid, block, 0, st, a, ep1, ep2);
-  else if (C == 128 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 128>), grid, block, 0, st, a, ep1, ep2);
-  else if (C == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 256>), grid, block, 0, st, a, ep1, ep2);
-  else hipLaunchKernelGGL((conv_chain_i8_kernel<256, 256>), grid, block, 0, st, a, ep1, ep2);
+  if (C2 == 0) {
+    if (C == 64 && K2 == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 64>), grid, block, 0, st, a, ep1, ep2);
+    else if (C == 64 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 128>), grid, block, 0, st, a, ep1, ep2);
+    else if (C == 128 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 128>), grid, block, 0, st, a, ep1, ep2);
+    else if (C == 128 && K2 == 256) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 256>), grid, block, 0, st, a, ep1, ep2);
+    else if (C == 256 && K2 == 256) hipLaunchKernelGGL((conv_chain_i8_kernel<256, 256>), grid, block, 0, st, a, ep1, ep2);
+    else return DLMCQ_EINVAL;
+  } else {
+    if (C == 64 && C2 == 64 && K2 == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 64, 64>), grid, block, 0, st, a, ep1, ep2);
+    else if (C == 128 && C2 == 256 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 128, 256>), grid, block, 0, st, a, ep1, ep2);
+    else return DLMCQ_EINVAL;
+  }
   return launch_status();
+}
+
+extern "C" int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                                          const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t M,
+                                          int64_t C, int64_t K, int32_t x_is_unsigned, const float* residual, int32_t relu,
+                                          void* codes, const float* q_scale, const float* q_zero_point, int32_t q_lo,
+                                          int32_t q_hi, int32_t q_form, float q_ste_g, const int8_t* w2, const float* bias2,
+                                          const int32_t* wsum2, const float* w_scale2, int64_t K2, int32_t relu2, void* codes2,
+                                          const float* q2_scale, const float* q2_zero_point, int32_t q2_lo, int32_t q2_hi,
+                                          int32_t q2_form, float q2_ste_g, int32_t rows_per_tile, dlmcq_stream_t stream) {
+  if (M < 0 || C < 1 || K < 1 || K2 < 1 || K % 64 != 0) return DLMCQ_EINVAL;
+  if (M == 0) return DLMCQ_OK;
+  if (!x || !w || !wsum || !in_scale || !w_scale || !residual || !w2 || !wsum2 || !w_scale2 || !codes2 || !q_scale || !q2_scale)
+    return DLMCQ_EINVAL;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(w2) || !aligned16(residual) || (out && !aligned16(out)) ||
+      (codes && !aligned16(codes)) || !aligned4(codes2))
+    return DLMCQ_EALIGN;
+  ChainArgs a{};
+  a.x = static_cast<const int8_t*>(x); a.w1 = w; a.s_w1 = w_scale; a.wsum1 = wsum; a.bias1 = bias;
+  a.s_in1 = in_scale; a.zp_in1 = in_zero_point; a.shift1 = x_is_unsigned ? 128 : 0;
+  a.residual = residual; a.out = out; a.codes = static_cast<uint8_t*>(codes);
+  a.w3 = w2; a.s_w3 = w_scale2; a.wsum3 = wsum2; a.bias3 = bias2; a.codes2 = static_cast<uint8_t*>(codes2);
+  return chain_launch(a, M, C, K, 0, K2, relu, codes, q_scale, q_zero_point, q_lo, q_hi, q_form, q_ste_g, relu2, codes2, q2_scale,
+                      q2_zero_point, q2_lo, q2_hi, q2_form, q2_ste_g, rows_per_tile, stream);
+}
+
+extern "C" int dlmcq_conv2d_i8_nhwc_dual_chain(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                                               const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N,
+                                               int64_t H, int64_t W, int64_t C, int64_t K, int32_t x_is_unsigned, const void* x2,
+                                               const int8_t* w2, const float* bias2, const int32_t* wsum2, const float* in_scale2,
+                                               const float* in_zero_point2, const float* w_scale2, int64_t H2, int64_t W2,
+                                               int64_t C2, int32_t stride2, int32_t x2_is_unsigned, int32_t relu, void* codes,
+                                               const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
+                                               int32_t q_form, float q_ste_g, const int8_t* w3, const float* bias3,
+                                               const int32_t* wsum3, const float* w_scale3, int64_t K3, int32_t relu3, void* codes3,
+                                               const float* q3_scale, const float* q3_zero_point, int32_t q3_lo, int32_t q3_hi,
+                                               int32_t q3_form, float q3_ste_g, int32_t rows_per_tile, dlmcq_stream_t stream) {
+  if (N < 0 || H < 1 || W < 1 || C < 1 || K < 1 || K3 < 1 || K % 64 != 0 || H2 < 1 || W2 < 1 || C2 < 1 || stride2 < 1)
+    return DLMCQ_EINVAL;
+  if ((H2 - 1) / stride2 + 1 != H || (W2 - 1) / stride2 + 1 != W) return DLMCQ_EINVAL;   // both pairs give [N, H, W, K]
+  const int64_t M = N * H * W;
+  if (M == 0) return DLMCQ_OK;
+  if (!x || !w || !wsum || !in_scale || !w_scale || !x2 || !w2 || !wsum2 || !in_scale2 || !w_scale2 || !w3 || !wsum3 || !w_scale3 ||
+      !codes3 || !q_scale || !q3_scale)
+    return DLMCQ_EINVAL;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(x2) || !aligned16(w2) || !aligned16(w3) || (out && !aligned16(out)) ||
+      (codes && !aligned16(codes)) || !aligned4(codes3))
+    return DLMCQ_EALIGN;
+  if (M >= (1ll << 31) || N * H2 * W2 * C2 >= (1ll << 40)) return DLMCQ_ERANGE;
+  ChainArgs a{};
+  a.x = static_cast<const int8_t*>(x); a.w1 = w; a.s_w1 = w_scale; a.wsum1 = wsum; a.bias1 = bias;
+  a.s_in1 = in_scale; a.zp_in1 = in_zero_point; a.shift1 = x_is_unsigned ? 128 : 0;
+  a.x2 = static_cast<const int8_t*>(x2); a.w2 = w2; a.s_w2 = w_scale2; a.wsum2 = wsum2; a.bias2 = bias2;
+  a.s_in2 = in_scale2; a.zp_in2 = in_zero_point2; a.shift2 = x2_is_unsigned ? 128 : 0;
+  a.P = (int)H; a.Q = (int)W; a.H2 = (int)H2; a.W2 = (int)W2; a.stride2 = stride2;
+  a.qdiv = make_fastdiv((uint32_t)W);
+  a.pdiv = make_fastdiv((uint32_t)H);
+  a.residual = nullptr; a.out = out; a.codes = static_cast<uint8_t*>(codes);
+  a.w3 = w3; a.s_w3 = w_scale3; a.wsum3 = wsum3; a.bias3 = bias3; a.codes2 = static_cast<uint8_t*>(codes3);
+  return chain_launch(a, M, C, K, C2, K3, relu, codes, q_scale, q_zero_point, q_lo, q_hi, q_form, q_ste_g, relu3, codes3, q3_scale,
+                      q3_zero_point, q3_lo, q3_hi, q3_form, q3_ste_g, rows_per_tile, stream);
 }

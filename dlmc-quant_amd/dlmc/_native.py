@@ -65,6 +65,10 @@ SIGNATURES = {
     "dlmcq_conv2d_i8_nhwc_chain": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p, _i32, _p, _p, _p, _i32,
                                                  _i32, _i32, _f32, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _i32, _f32,
                                                  _i32, _p]),
+    "dlmcq_conv2d_i8_nhwc_dual_chain": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i32,
+                                                      _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32,
+                                                      _i32, _p, _p, _p, _i32, _i32, _i32, _f32,
+                                                      _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _i32, _p]),
     "dlmcq_quantize_pad_nhwc4": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32,
                                                _i32, _f32, _p]),
     "dlmcq_quantize_weight_stem_i8": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i32, _p]),

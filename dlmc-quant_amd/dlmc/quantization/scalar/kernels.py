@@ -594,6 +594,63 @@ def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_co
     return out, codes, codes2
 
 
+DUAL_CHAIN_SHAPES = {(64, 64, 64), (128, 256, 128)}   # (C, C2, K3) triples dlmcq_conv2d_i8_nhwc_dual_chain is built for
+
+
+def dual_chain_supported(c, c2, k, k3, m):
+    return (c, c2, k3) in DUAL_CHAIN_SHAPES and k % 64 == 0 and m * k * 4 <= 0x7fff0000
+
+
+def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_codes=False, relu3=True, emit3=None, rows_per_tile=0):
+    """conv1x1(a) + conv1x1(b, strided) (+ ReLU, the consumer's quantiser `emit`) and the next 1x1 convolution `c3` on the
+    codes, in one kernel (dlmcq_conv2d_i8_nhwc_dual_chain).  `a`, `b`: operand dicts as for conv2d_i8_dual (`b` may carry a
+    stride); `c3`: wq, wsum, bias, w_scale.  Returns (out or None, codes or None, codes3)."""
+    ca, cb = a["codes"], b["codes"]
+    N.require_gpu(ca, cb, a["wq"], b["wq"], c3["wq"])
+    if not ca.is_contiguous(memory_format=torch.channels_last):
+        ca = ca.contiguous(memory_format=torch.channels_last)
+    if not cb.is_contiguous(memory_format=torch.channels_last):
+        cb = cb.contiguous(memory_format=torch.channels_last)
+    n, ch, h, w_ = ca.shape
+    _, ch2, h2, w2 = cb.shape
+    K_, K3 = a["wq"].shape[0], c3["wq"].shape[0]
+    st2 = int(b.get("stride", 1))
+    if (tuple(a["wq"].shape[1:3]), tuple(b["wq"].shape[1:3]), tuple(c3["wq"].shape[1:3])) != ((1, 1),) * 3 or int(a.get("stride", 1)) != 1 \
+            or int(a.get("padding", 0)) or int(b.get("padding", 0)) or b["wq"].shape[0] != K_ or c3["wq"].shape[3] != K_ or emit is None \
+            or emit3 is None:
+        raise ValueError("conv2d_i8_dual_chain: three unpadded 1x1 convolutions, the third reading the codes of the sum of the first two")
+
+    def alloc(k, dtype):
+        return torch.empty((n, k, h, w_), dtype=dtype, device=ca.device, memory_format=torch.channels_last)
+    out = alloc(K_, torch.float32) if want_out else None
+    codes = alloc(K_, emit.dtype) if want_codes else None
+    codes3 = alloc(K3, emit3.dtype)
+
+    def vec(t, k):
+        t = _f32c(t.detach(), ca).reshape(-1)
+        return t.expand(k).contiguous() if t.numel() == 1 else t
+
+    def small(t):
+        return None if t is None else _f32c(t.detach() if hasattr(t, "detach") else t, ca).reshape(-1)
+
+    def bias_of(t):
+        return None if t["bias"] is None else t["bias"].detach().contiguous()
+    wsa, wsb, ws3 = vec(a["w_scale"], K_), vec(b["w_scale"], K_), vec(c3["w_scale"], K3)
+    sia, zpa, sib, zpb = small(a["in_scale"]), small(a["in_zp"]), small(b["in_scale"]), small(b["in_zp"])
+    ba, bb, b3 = bias_of(a), bias_of(b), bias_of(c3)
+    qs, qz, qs3, qz3 = small(emit.scale), small(emit.zero_point), small(emit3.scale), small(emit3.zero_point)
+    m = n * h * w_
+    nbytes = ca.numel() + cb.numel() // (st2 * st2) + a["wq"].numel() + b["wq"].numel() + c3["wq"].numel() + \
+        m * K_ * (4 * want_out + want_codes) + m * K3
+    PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_dual_chain(
+        N.ptr(ca), N.ptr(a["wq"]), N.ptr(out), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa), n, h, w_, ch, K_,
+        int(ca.dtype == torch.uint8), N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2,
+        ch2, st2, int(cb.dtype == torch.uint8), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi, emit.form, emit.g,
+        N.ptr(c3["wq"]), N.ptr(b3), N.ptr(c3["wsum"]), N.ptr(ws3), K3, int(bool(relu3)), N.ptr(codes3), N.ptr(qs3), N.ptr(qz3), emit3.lo,
+        emit3.hi, emit3.form, emit3.g, int(rows_per_tile), N.stream_ptr())))
+    return out, codes, codes3
+
+
 def quantize_pad_nhwc4(x, scale, zero_point, lo, hi, form, pad, g=0.0):
     """Image batch (N, C <= 4, H, W) fp32, any memory format -> activation codes in a zero-point-padded NHWC
     buffer, 4 bytes per pixel: uint8/int8 tensor (N, H + 2 pad, W + 2 pad, 4) (a view of a slightly larger

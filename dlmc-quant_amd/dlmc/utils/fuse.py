@@ -359,25 +359,37 @@ class DualInt8Layer(nn.Module):
 
 class ChainInt8Layer(nn.Module):
     """A residual block's last 1x1 convolution (+ shortcut, ReLU) and the next block's first 1x1 convolution as ONE kernel
-    (csrc/conv_chain_i8.hip): the activation codes between them stay in LDS.  Returns `(fp32 or None, codes or None, codes2)`;
-    shapes the kernel is not built for run the two plan nodes one after the other."""
+    (csrc/conv_chain_i8.hip): the activation codes between them stay in LDS.  The shortcut is an fp32 tensor, or - `short`,
+    the first block of a stage - a second 1x1 convolution reduced into the same tile.  Returns
+    `(fp32 or None, codes or None, codes2)`; shapes the kernel is not built for run the plan nodes one after the other."""
 
-    def __init__(self, a, b, want_codes):
+    def __init__(self, a, b, want_codes, short=None, main=None):
         super().__init__()
-        self.a, self.b, self.want_codes = a, b, bool(want_codes)
+        # `a` carries the epilogue options; with a convolution shortcut, `main` / `short` are the unit-stride and the (possibly)
+        # strided operand of the sum (fp32 addition commutes: which of the two the dual plan node called `a` does not matter)
+        self.a, self.b, self.want_codes, self.short, self.main = a, b, bool(want_codes), short, (main if main is not None else a)
+        self.swapped = short is not None and self.main is not a       # main reads the plan node's SECOND input
 
-    def forward(self, x, residual):
-        a, b = self.a, self.b
-        codes = a._codes(x)
+    def forward(self, x, y):
+        a, b, sc, mn = self.a, self.b, self.short, self.main
+        if self.swapped:
+            x, y = y, x
+        codes = mn._codes(x)
         n, c, h, w = codes.shape
-        if not K.chain_supported(c, a.k, b.k, n * h * w):
-            out, mid = a(x, residual)
+        nxt = dict(wq=b.wq, wsum=b.wsum, bias=b._bias(), w_scale=b.w_scale)
+        kw = dict(relu=a.relu, emit=a._emit_for(n, a.k, h, w), want_out=a.want_out, want_codes=self.want_codes, emit2=b._emit_for(n, b.k, h, w))
+        if sc is None:
+            if not K.chain_supported(c, a.k, b.k, n * h * w):
+                out, mid = a(x, y)
+                return out, (mid if self.want_codes else None), b(mid)[1]
+            oa = dict(codes=codes, wq=a.wq, wsum=a.wsum, bias=a._bias(), in_scale=a._in_scale(a._real_numel(codes)), in_zp=a.act.zp,
+                      w_scale=a.w_scale)
+            return K.conv2d_i8_chain(oa, nxt, y, relu2=b.relu, **kw)
+        if not K.dual_chain_supported(c, sc.c, a.k, b.k, n * h * w):
+            out, mid = DualInt8Layer(a, sc if mn is a else mn)(*((x, y) if mn is a else (y, x)))
             return out, (mid if self.want_codes else None), b(mid)[1]
-        oa = dict(codes=codes, wq=a.wq, wsum=a.wsum, bias=a._bias(), in_scale=a._in_scale(a._real_numel(codes)), in_zp=a.act.zp,
-                  w_scale=a.w_scale)
-        ob = dict(wq=b.wq, wsum=b.wsum, bias=b._bias(), w_scale=b.w_scale)
-        return K.conv2d_i8_chain(oa, ob, residual, relu=a.relu, emit=a._emit_for(n, a.k, h, w), want_out=a.want_out,
-                                 want_codes=self.want_codes, relu2=b.relu, emit2=b._emit_for(n, b.k, h, w))
+        kw["emit3"] = kw.pop("emit2")
+        return K.conv2d_i8_dual_chain(mn.operand(x), sc.operand(y), nxt, relu3=b.relu, **kw)
 
 
 def _pointwise(plan):
@@ -395,11 +407,22 @@ def _chain_pass(gm, report):
     modules = dict(gm.named_modules())
     count = 0
     for na in list(graph.nodes):
-        if na.op != "call_module" or len(na.args) != 2 or not isinstance(modules.get(na.target), Int8Layer):
+        if na.op != "call_module" or len(na.args) != 2 or not isinstance(modules.get(na.target), (Int8Layer, DualInt8Layer)):
             continue
-        a = modules[na.target]
-        if not (_pointwise(a) and a.emit is not None and (a.emit.lo, a.emit.hi) == (0, 255) and not a.emit.needs_g):
+        a, main, short = modules[na.target], None, None
+        if isinstance(a, DualInt8Layer):      # the first block of a stage: its shortcut is a (possibly strided) 1x1 convolution
+            a, other = a.a, a.b
+            main, short = (a, other) if _pointwise(a) else (other, a)
+            lay = short.layer
+            if not (_pointwise(main) and type(short) is Int8Layer and lay.weight.dim() == 4 and tuple(lay.weight.shape[2:]) == (1, 1) and
+                    lay.padding[0] == 0 and short.w_off is None and short.pool is None and short.k_pad == short.k and
+                    short.c_pad == short.c and not short.act.needs_g and a.pool is None and a.w_off is None):
+                continue
+        elif not _pointwise(a):
             continue
+        if not (a.emit is not None and (a.emit.lo, a.emit.hi) == (0, 255) and not a.emit.needs_g):
+            continue
+        mc = (main if main is not None else a).c       # channels of the unit-stride operand
         gets = {u.args[1]: u for u in na.users if u.op == "call_function" and u.target is operator.getitem}
         if len(gets) != len(na.users) or 1 not in gets:
             continue
@@ -407,7 +430,8 @@ def _chain_pass(gm, report):
         nb = next((u for u in g1.users if u.op == "call_module" and u.args == (g1,) and isinstance(modules.get(u.target), Int8Layer) and
                    _pointwise(modules[u.target]) and modules[u.target].emit is not None and not modules[u.target].want_out and
                    not modules[u.target].emit.needs_g and modules[u.target].c == a.k and
-                   (a.c, modules[u.target].k) in K.CHAIN_SHAPES), None)
+                   ((mc, modules[u.target].k) in K.CHAIN_SHAPES if short is None else
+                    (mc, short.c, modules[u.target].k) in K.DUAL_CHAIN_SHAPES)), None)
         if nb is None:
             continue
         b = modules[nb.target]
@@ -416,7 +440,7 @@ def _chain_pass(gm, report):
             continue
         name = f"_int8_chain_{count}"
         count += 1
-        gm.add_module(name, ChainInt8Layer(a, b, want_codes=len(g1.users) > 1))
+        gm.add_module(name, ChainInt8Layer(a, b, want_codes=len(g1.users) > 1, short=short, main=main))
         with graph.inserting_after(na):
             nc = graph.call_module(name, args=na.args)
         with graph.inserting_after(nc):

@@ -401,6 +401,27 @@ int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float* out, const
                                const float* q2_scale, const float* q2_zero_point, int32_t q2_lo, int32_t q2_hi,
                                int32_t q2_form, float q2_ste_g, int32_t rows_per_tile, dlmcq_stream_t stream);
 
+/*
+ * dlmcq_conv2d_i8_nhwc_chain for a block whose shortcut is itself a 1x1 convolution (the first block of a stage): the
+ * first layer is dlmcq_conv2d_i8_nhwc_dual restricted to two 1x1 convolutions,
+ *     v = conv1x1(x, w) + bias  +  conv1x1(x2 sampled at stride2, w2) + bias2;  ReLU;  out = v (optional);  codes = Q(v) (optional)
+ *     codes3 = Q3( ReLU?( conv1x1( Q(v), w3 ) + bias3 ) )
+ * bit-identical to dlmcq_conv2d_i8_nhwc_dual followed by dlmcq_conv2d_i8_nhwc_fused on its codes.  x: [N][H][W][C] codes
+ * (stride 1); x2: [N][H2][W2][C2] codes with (H2 - 1) / stride2 + 1 == H (likewise W); w: [K][C]; w2: [K][C2]; w3: [K3][K].
+ * Supported: (C, C2, K3) in {(64, 64, 64), (128, 256, 128)}; K % 64 == 0; N*H*W*K*4 < 2^31 - 64 Ki.
+ */
+int dlmcq_conv2d_i8_nhwc_dual_chain(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                                    const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N,
+                                    int64_t H, int64_t W, int64_t C, int64_t K, int32_t x_is_unsigned, const void* x2,
+                                    const int8_t* w2, const float* bias2, const int32_t* wsum2, const float* in_scale2,
+                                    const float* in_zero_point2, const float* w_scale2, int64_t H2, int64_t W2, int64_t C2,
+                                    int32_t stride2, int32_t x2_is_unsigned, int32_t relu, void* codes, const float* q_scale,
+                                    const float* q_zero_point, int32_t q_lo, int32_t q_hi, int32_t q_form, float q_ste_g,
+                                    const int8_t* w3, const float* bias3, const int32_t* wsum3, const float* w_scale3,
+                                    int64_t K3, int32_t relu3, void* codes3, const float* q3_scale, const float* q3_zero_point,
+                                    int32_t q3_lo, int32_t q3_hi, int32_t q3_form, float q3_ste_g, int32_t rows_per_tile,
+                                    dlmcq_stream_t stream);
+
 /* ---- the 3-channel first layer and its max-pool, in the integer-code domain (csrc/conv_stem_i8.hip) ---- */
 
 /*

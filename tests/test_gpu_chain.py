@@ -58,6 +58,43 @@ def test_chain_larger_batch_and_nonzero_zero_points():
     assert torch.equal(codes, codes_r) and torch.equal(codes2, codes2_r)
 
 
+@pytest.mark.parametrize("c,c2,k,k3,stride", [(64, 64, 256, 64, 1), (128, 256, 512, 128, 2)])
+def test_dual_chain_matches_dual_plus_fused(c, c2, k, k3, stride):
+    """First block of a stage: conv3 + downsample convolution + ReLU + quantiser + the next block's conv1 in one kernel, against
+    dlmcq_conv2d_i8_nhwc_dual followed by dlmcq_conv2d_i8_nhwc_fused."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(c + k3)
+    n, h = 3, 13                                  # 507 pixels: a partial last tile
+    h2 = (h - 1) * stride + 1 + (stride - 1)      # 13 (stride 1) / 26 (stride 2: the last row and column are skipped)
+
+    def operand(ch, hh, kk, zp, st):
+        x = torch.randint(0, 256, (n, ch, hh, hh), generator=g, device=dev, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+        wq = torch.randint(-127, 128, (kk, 1, 1, ch), generator=g, device=dev, dtype=torch.int8)
+        return dict(codes=x, wq=wq, wsum=wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous(),
+                    bias=torch.randn(kk, generator=g, device=dev), in_scale=torch.full((1,), 0.02, device=dev),
+                    in_zp=torch.full((1,), zp, device=dev), w_scale=(torch.rand(kk, generator=g, device=dev) * 0.004 + 0.001), stride=st)
+    a, b = operand(c, h, k, 2.0, 1), operand(c2, h2, k, 5.0, stride)
+    w3 = torch.randint(-127, 128, (k3, 1, 1, k), generator=g, device=dev, dtype=torch.int8)
+    c3 = dict(wq=w3, wsum=w3.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous(), bias=torch.randn(k3, generator=g, device=dev),
+              w_scale=(torch.rand(k3, generator=g, device=dev) * 0.002 + 0.0005))
+    emit = K.EmitCodes(torch.full((1,), 0.07, device=dev), torch.full((1,), 4.0, device=dev), 0, 255, N.FORM_ZEROPOINT)
+    emit3 = K.EmitCodes(torch.full((1,), 0.13, device=dev), torch.zeros(1, device=dev), 0, 255, N.FORM_ZEROPOINT)
+    out_r, codes_r = K.conv2d_i8_dual(a, b, relu=True, emit=emit, want_out=True)
+    _, codes3_r = K.conv2d_i8(codes_r, c3["wq"], c3["wsum"], c3["bias"], emit.scale, emit.zero_point, c3["w_scale"], relu=True,
+                              emit=emit3, want_out=False)
+    assert K.dual_chain_supported(c, c2, k, k3, n * h * h)
+    for want_out, want_codes in ((True, False), (True, True), (False, True)):
+        out, codes, codes3 = K.conv2d_i8_dual_chain(a, b, c3, relu=True, emit=emit, want_out=want_out, want_codes=want_codes,
+                                                    relu3=True, emit3=emit3)
+        if want_out:
+            assert torch.equal(out.view(torch.int32), out_r.view(torch.int32))
+        if want_codes:
+            assert torch.equal(codes, codes_r)
+        assert torch.equal(codes3, codes3_r)
+
+
 def test_chain_refuses_unsupported_shapes():
     K, a, b, res, emit, emit2 = _case(1, 7, 64, 256, 64, seed=1)
     assert K.chain_supported(64, 256, 64, 49) and not K.chain_supported(512, 2048, 512, 49)
@@ -92,11 +129,12 @@ def test_resnet50_plan_chains_the_block_boundaries_and_stays_bit_identical():
         plain = fuse_inference(net, chain_pairs=False)
         chained = fuse_inference(net)
         rep = chained.fusion_report
-        # 16 blocks: 4 dual block ends (not chained yet), the very last one has no successor, the 1024 -> 512 stage end is
-        # wider than the kernel is built for, stage 4 altogether: 9 pairs, 2 of them stage ends that still write their codes
-        assert plain.fusion_report.chained == 0 and rep.chained == 9, rep
+        # 16 blocks: the very last one has no successor; stage 3's and stage 4's first blocks, the 1024 -> 512 stage end and the
+        # rest of stage 4 are wider than the kernel is built for: 11 pairs, 2 of them first blocks of a stage (shortcut =
+        # convolution), 2 stage ends that still write their codes for the next stage's downsample convolution
+        assert plain.fusion_report.chained == 0 and rep.chained == 11, rep
         pairs = [m for m in chained.modules() if isinstance(m, ChainInt8Layer)]
-        assert len(pairs) == 9 and sum(m.want_codes for m in pairs) == 2
+        assert len(pairs) == 11 and sum(m.want_codes for m in pairs) == 2 and sum(m.short is not None for m in pairs) == 2
         y0, y1 = plain(x * 0.8), chained(x * 0.8)
     assert torch.equal(y0.view(torch.int32), y1.view(torch.int32))
     assert torch.equal(y1.view(torch.int32), want.view(torch.int32))
