@@ -7,18 +7,21 @@
 A step = one forward of the quantised ResNet-50 (54 quantised layers, FSPTQ forms: weights minmax_channel s8, activations
 minmax_tensor u8, BatchNorm folded first as FSPTQuant.py:67 does) over 512 synthetic 224x224 images per GPU, scales frozen
 (the observer pass and its all-reduce run once, before the timed region).  Default mode = the frozen execution plan of
-dlmc/utils/fuse.py: every layer is ONE launch of the int8 MFMA kernel (csrc/conv_i8.hip) whose epilogue dequantises, adds
-the shortcut, applies ReLU and emits the NEXT layer's activation codes; weight codes are quantised once, when the plan is
+dlmc/utils/fuse.py: every layer is ONE launch of an int8 MFMA kernel (csrc/conv_i8.hip) whose epilogue dequantises, adds
+the shortcut, applies ReLU and emits the NEXT layer's activation codes, and 11 block boundaries run their two layers as one
+launch (csrc/conv_chain_i8.hip); weight codes are quantised once, when the plan is
 built (the reference re-quantises 0.2 GB of weights per forward: 0.5 % of the step's bytes).  `--plan modules` and
 `--conv fp32` run the reference's own op sequence (stand-alone fake-quant kernels + MIOpen convolutions).
 Inputs are resident in HBM when the timed region starts.  Weak scaling by default (512 images on every GPU, no collective
 in the steady state); `--scaling strong` splits a fixed global batch of 4096.
 
 One JSON line on rank 0.  Besides the contract fields:
-  roofline             the kernel with the largest share of the step (the int8 MFMA kernel with its fused epilogue):
+  roofline             the kernel with the largest share of the step - since round 2 the chain kernel (a block's last 1x1
+                       convolution + shortcut + ReLU + quantiser + the next block's first 1x1, csrc/conv_chain_i8.hip):
                        algorithmic bytes / HIP-event durations of its launches in the first timed step, on the launch stream;
                        `traffic` comes from the committed rocprofv3 PMC passes of the same command (`traffic_measured_in_run`
                        says so: counters cannot be read from inside the process)
+  roofline_second_kernel  the same for the other int8 kernel (csrc/conv_i8.hip: 3x3s, stage 3 / 4 block ends, first 1x1s, fc)
   roofline_fake_quant  the stand-alone fake-quant kernel, measured live on BASELINE configs[1]'s tensor
   cpu_baseline         the CPU port of the same layer stack (oracle/), timed on this box's host cores on a bounded sample
                        (N = 1 only): all granted cores and one thread, median and min
@@ -264,29 +267,47 @@ def main():
     fq_roof = roof("fq_tensor", fq, "fq_tensor_kernel<ZEROPOINT> (per-tensor activation fake-quant"
                    + (", int8 code emission: 5 B/elem)" if args.int8 else ": 8 B/elem)"))
     conv = fam.get("conv_i8", empty)
-    conv_ops = 0
-    if conv["ms"] > 0:
-        macs = sum(r[4] for r in W.layer_table(W.MODELS[args.model](), torch.zeros(1, 3, 224, 224))
-                   if r[3][1] % 64 == 0 and (len(r[3]) == 2 or r[2][1] == r[3][1]))   # the layers on the int8 kernel (dense, C % 64 == 0)
-        conv_ops = 2 * macs * args.batch * psteps
+    chain = fam.get("conv_chain", empty)          # block end + next 1x1 in one kernel (csrc/conv_chain_i8.hip)
+    conv_ops = chain_ops = 0
+    if conv["ms"] > 0 or chain["ms"] > 0:
+        table = W.layer_table(W.MODELS[args.model](), torch.zeros(1, 3, 224, 224))
+        macs = sum(r[4] for r in table if r[3][1] % 64 == 0 and (len(r[3]) == 2 or r[2][1] == r[3][1]))   # the layers on the int8 kernels (dense, C % 64 == 0)
+        chain_macs = 0
+        if chain["ms"] > 0:
+            from dlmc.utils.fuse import ChainInt8Layer
+            by_shape = {r[3]: r[4] for r in table}       # (in ResNets a weight shape occurs at one resolution only)
+            plan_mod = model.plan if hasattr(model, "plan") else model
+            chain_macs = sum(by_shape[tuple(p.layer.weight.shape)] for c in plan_mod.modules() if isinstance(c, ChainInt8Layer)
+                             for p in (c.main, c.short, c.b) if p is not None)
+        conv_ops = 2 * (macs - chain_macs) * args.batch * psteps
+        chain_ops = 2 * chain_macs * args.batch * psteps
     # `roofline` describes the kernel of this project with the largest share of the timed region
-    if conv["ms"] > fq["ms"]:
+    second_roof = None
+    if max(conv["ms"], chain["ms"]) > fq["ms"]:
         if args.fused:
-            main_roof = roof("conv_i8", conv, "conv_i8_mfma_kernel (int8 implicit-GEMM conv/linear; epilogue: dequant + residual + ReLU + "
-                                              "next layer's activation codes)",
-                             "algorithmic bytes per launch = int8 input + int8 weights + what the epilogue moves (1 B/elem codes, "
-                             "4 B/elem fp32 output where a shortcut / pool needs it, 4 B/elem residual read)", ops=conv_ops)
+            note = ("algorithmic bytes per launch = int8 input + int8 weights + what the epilogue moves (1 B/elem codes, "
+                    "4 B/elem fp32 output where a shortcut / pool needs it, 4 B/elem residual read)")
+            conv_roof = roof("conv_i8", conv, "conv_i8_mfma_kernel (int8 implicit-GEMM conv/linear; epilogue: dequant + residual + ReLU + "
+                                              "next layer's activation codes)", note, ops=conv_ops)
+            chain_roof = roof("conv_chain", chain, "conv_chain_i8_kernel (a block's last 1x1 convolution + shortcut + ReLU + quantiser and the "
+                                                   "next block's first 1x1 convolution in one launch; the code tensor between them stays in LDS)",
+                              "algorithmic bytes per launch = int8 inputs + int8 weights of both (three) convolutions + 4 B/elem fp32 shortcut read "
+                              "+ 4 B/elem fp32 output (1 B/elem codes at stage ends) + the second convolution's codes", ops=chain_ops)
+            main_roof, second_roof = (chain_roof, conv_roof) if chain["ms"] > conv["ms"] else (conv_roof, chain_roof if chain["ms"] > 0 else None)
         else:
             main_roof = roof("conv_i8", conv, "conv_i8_mfma_kernel (fused int8-dequant x GEMM conv/linear, fp32 NHWC out)",
                              "algorithmic bytes = int8 input + int8 weights + fp32 output per launch; the 1x1 layers are bound by "
                              "the fp32 output stream, the 3x3 layers by the MFMA pipeline (see conv_i8.TOPs)", ops=conv_ops)
     else:
         main_roof = fq_roof
-    if args.fused and conv["ms"] > fq["ms"] and args.model == "resnet50" and args.batch == 512:
-        main_roof["traffic"], src = pmc_traffic("conv_i8_mfma_kernel")
-        main_roof["traffic_measured_in_run"] = False
-        if src:
-            main_roof["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
+    if args.fused and max(conv["ms"], chain["ms"]) > fq["ms"] and args.model == "resnet50" and args.batch == 512:
+        for r in (main_roof, second_roof):
+            if r is None:
+                continue
+            r["traffic"], src = pmc_traffic(r["kernel"].split(" ")[0])
+            r["traffic_measured_in_run"] = False
+            if src:
+                r["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
     if args.fused:
         # In the fused plan the activation quantiser lives in the conv epilogue, so the stand-alone fake-quant kernel
         # hardly appears in the step.  Its own roofline is measured here, live, on BASELINE configs[1]'s tensor
@@ -323,11 +344,12 @@ def main():
         "config": {"workload": f"{args.model} W8A8 per-channel fake-quant forward (FSPTQ forms: W minmax_channel s8, "
                                f"A minmax_tensor u8), {'BatchNorm kept' if args.keep_bn else 'BN folded first as in FSPTQuant.py:67'}, "
                                f"{'fused int8 MFMA conv/linear' if args.int8 else 'fp32 conv of the fake-quantised operands'}, "
-                               f"{'frozen execution plan (epilogue-fused ReLU / shortcut / next-layer codes; weight codes quantised once at plan build), ' if args.fused else ''}"
+                               f"{'frozen execution plan (epilogue-fused ReLU / shortcut / next-layer codes; block end + next 1x1 as one launch; weight codes quantised once at plan build), ' if args.fused else ''}"
                                f"{str(args.streams) + ' HIP streams per GPU (the ' + str(min(args.profiled_steps, args.steps)) + ' profiled step(s) on one), ' if args.fused and args.streams > 1 else ''}"
                                f"224x224 {'relu(N(0,1))' if args.input == 'halfnormal' else 'N(0,1)'} pixels, batch {args.batch} per GPU, scales frozen",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},
         "roofline": main_roof,
+        **({"roofline_second_kernel": second_roof} if second_roof else {}),
         "roofline_fake_quant": fq_roof,
         "quant_path": {"images_per_s": round(args.batch * psteps / (qms * 1e-3), 1) if qms else None,
                        "GBps": round(qbytes / (qms * 1e-3) / 1e9, 1) if qms else None,
@@ -336,10 +358,11 @@ def main():
                        "families": {k: {"launches": f["launches"], "GBps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)}
                                     for k, f in fam.items() if f["ms"] > 0}},
     }
-    if conv["ms"] > 0:
-        out["conv_i8"] = {"launches": conv["launches"], "ms_per_step": round(conv["ms"] / psteps, 3),
-                          "GBps": round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9, 1),
-                          "TOPs": round(conv_ops / (conv["ms"] * 1e-3) / 1e12, 1), "peak_TOPs_dense_i8": MFMA_I8_PEAK_TOPS}
+    if conv["ms"] + chain["ms"] > 0:     # both int8 matrix-core kernels together
+        out["conv_i8"] = {"launches": conv["launches"] + chain["launches"], "ms_per_step": round((conv["ms"] + chain["ms"]) / psteps, 3),
+                          "GBps": round((conv["bytes"] + chain["bytes"]) / ((conv["ms"] + chain["ms"]) * 1e-3) / 1e9, 1),
+                          "TOPs": round((conv_ops + chain_ops) / ((conv["ms"] + chain["ms"]) * 1e-3) / 1e12, 1),
+                          "peak_TOPs_dense_i8": MFMA_I8_PEAK_TOPS}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_batch, fold_bn=not args.keep_bn, halfnormal=args.input == "halfnormal")
     print(json.dumps(out), flush=True)

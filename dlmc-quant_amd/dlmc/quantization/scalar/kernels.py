@@ -586,7 +586,7 @@ def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_co
     qs, qz = _f32c(emit.scale.detach(), c).reshape(-1), None if emit.zero_point is None else _f32c(emit.zero_point, c).reshape(-1)
     qs2, qz2 = _f32c(emit2.scale.detach(), c).reshape(-1), None if emit2.zero_point is None else _f32c(emit2.zero_point, c).reshape(-1)
     nbytes = c.numel() + a["wq"].numel() + b["wq"].numel() + m * K_ * (4 + 4 * want_out + want_codes) + m * K2
-    PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_chain(
+    PROFILE.launch("conv_chain", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_chain(
         N.ptr(c), N.ptr(a["wq"]), N.ptr(out), N.ptr(b1), N.ptr(a["wsum"]), N.ptr(si), N.ptr(zp), N.ptr(ws1), m, ch, K_,
         int(c.dtype == torch.uint8), N.ptr(residual), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi,
         emit.form, emit.g, N.ptr(b["wq"]), N.ptr(b2), N.ptr(b["wsum"]), N.ptr(ws2), K2, int(bool(relu2)), N.ptr(codes2),
@@ -642,7 +642,7 @@ def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_cod
     m = n * h * w_
     nbytes = ca.numel() + cb.numel() // (st2 * st2) + a["wq"].numel() + b["wq"].numel() + c3["wq"].numel() + \
         m * K_ * (4 * want_out + want_codes) + m * K3
-    PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_dual_chain(
+    PROFILE.launch("conv_chain", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_dual_chain(
         N.ptr(ca), N.ptr(a["wq"]), N.ptr(out), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa), n, h, w_, ch, K_,
         int(ca.dtype == torch.uint8), N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2,
         ch2, st2, int(cb.dtype == torch.uint8), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi, emit.form, emit.g,

@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- pyt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/fetch.log" 2>&1 || echo "fetch pass failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/write.log" 2>&1 || echo "write pass failed"
 cd "$GRAFT_REPO_ROOT"
-python3 tools/pmc_summary.py --tail conv_i8_mfma_kernel 49 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
+python3 tools/pmc_summary.py --tail conv_chain_i8_kernel 11 --tail conv_i8_mfma_kernel 27 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
 python3 tools/plan_profile.py resnet50 512 > "$OUT/plan_profile_resnet50_b512.txt" 2>&1
 python3 tools/conv_lab.py --knobs 128:1,64:1,128:0,64:0 > "$OUT/conv_lab_resnet50_layers.txt" 2>&1
 python3 tools/conv_trace.py 512 256 14 256 3 > "$OUT/conv_trace_3x3_256_14.txt" 2>&1

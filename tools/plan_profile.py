@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 import workloads as W  # noqa: E402
 from bench import QCFG  # noqa: E402
-from dlmc.utils.fuse import DualInt8Layer, _PlanLayer as Int8Layer, fuse_inference  # noqa: E402
+from dlmc.utils.fuse import ChainInt8Layer, DualInt8Layer, _PlanLayer as Int8Layer, fuse_inference  # noqa: E402
 from dlmc.utils.merge_bn import merge_bn  # noqa: E402
 from dlmc.utils.quantize import quantize_model  # noqa: E402
 
@@ -37,8 +37,14 @@ with torch.no_grad():
         e.record()
         recs.append((mod, args, out, mod._ev, e))
     duals = [m for m in plan.modules() if isinstance(m, DualInt8Layer)]
+    chains = [m for m in plan.modules() if isinstance(m, ChainInt8Layer)]
+    inner = set()
+    for d in duals:
+        inner |= {id(d.a), id(d.b)}
+    for c in chains:
+        inner |= {id(c.a), id(c.b), id(c.main), id(c.short)}
     for m in plan.modules():
-        if isinstance(m, DualInt8Layer) or (isinstance(m, Int8Layer) and not any(m is d.a or m is d.b for d in duals)):
+        if isinstance(m, (DualInt8Layer, ChainInt8Layer)) or (isinstance(m, Int8Layer) and id(m) not in inner):
             m.register_forward_pre_hook(pre)
             m.register_forward_hook(post)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -51,6 +57,23 @@ tot = 0.0
 for mod, args, out, s, e in recs:
     us = s.elapsed_time(e) * 1e3
     tot += us
+    if isinstance(mod, ChainInt8Layer):
+        w1, w3 = mod.main.layer.weight, mod.b.layer.weight
+        o = out[2]
+        m_ = o.numel() // o.shape[1]
+        macs = m_ * (w1.numel() + w3.numel())
+        nb = args[0].numel() + w1.numel() + w3.numel() + m_ * w1.shape[0] * (4 * (out[0] is not None) + (out[1] is not None)) + o.numel()
+        what = f"+ fp32 shortcut {tuple(args[1].shape)}"
+        if mod.short is not None:
+            w2 = mod.short.layer.weight
+            macs += m_ * w2.numel()
+            nb += args[1].numel() // (mod.short.layer.stride[0] ** 2) + w2.numel()
+            what = f"+ {tuple(args[1].shape)} x {tuple(w2.shape)}"
+        else:
+            nb += m_ * w1.shape[0] * 4
+        print(f"{us:8.1f} us  CHAIN {str(tuple(args[0].shape)):20s} x {str(tuple(w1.shape)):18s} {what:42s} -> x {str(tuple(w3.shape)):18s} "
+              f"{'out ' if out[0] is not None else '    '}{'codes ' if out[1] is not None else '      '}{2 * macs / us / 1e6:6.0f} TOP/s {nb / us / 1e3:6.0f} GB/s")
+        continue
     if isinstance(mod, DualInt8Layer):
         wa, wb = mod.a.layer.weight, mod.b.layer.weight
         o = out[0] if out[0] is not None else out[1]

@@ -23,10 +23,10 @@ def family(name):
 
 
 args = sys.argv[1:]
-tail = None
-if "--tail" in args:       # --tail SUBSTRING N: also sum the LAST N dispatches whose kernel name contains SUBSTRING
+tails = []
+while "--tail" in args:    # --tail SUBSTRING N (repeatable): also sum the LAST N dispatches whose kernel name contains SUBSTRING
     i = args.index("--tail")
-    tail = (args[i + 1], int(args[i + 2]))
+    tails.append((args[i + 1], int(args[i + 2])))
     del args[i:i + 3]
 out = defaultdict(dict)
 for d in args:
@@ -35,7 +35,7 @@ for d in args:
         rows = list(csv.DictReader(open(path)))
         for row in rows:
             acc[(family(row["Kernel_Name"]), row["Counter_Name"])].append(float(row["Counter_Value"]))
-        if tail:
+        for tail in tails:
             sel = sorted((r for r in rows if tail[0] in r["Kernel_Name"]), key=lambda r: int(r["Dispatch_Id"]))[-tail[1]:]
             for c in {r["Counter_Name"] for r in sel}:
                 v = [float(r["Counter_Value"]) for r in sel if r["Counter_Name"] == c]
