@@ -99,7 +99,7 @@ def _check_codes(got_codes, fp32_out, ref32, emit, what):
 def test_resnet50_batch512_every_plan_node_against_the_oracle():
     import workloads as W
     from dlmc import _native as N
-    from dlmc.utils.fuse import DualInt8Layer, Int8Layer, StemLayer, fuse_inference
+    from dlmc.utils.fuse import ChainInt8Layer, DualInt8Layer, Int8Layer, StemLayer, fuse_inference
     from dlmc.utils.merge_bn import merge_bn
     from dlmc.utils.quantize import quantize_model
     batch = 512
@@ -112,16 +112,23 @@ def test_resnet50_batch512_every_plan_node_against_the_oracle():
         model(x)
         plan = fuse_inference(model)
         duals = [m for m in plan.modules() if isinstance(m, DualInt8Layer)]
+        chains = [m for m in plan.modules() if isinstance(m, ChainInt8Layer)]
         inner = {id(d.a) for d in duals} | {id(d.b) for d in duals}
+        for c in chains:
+            inner |= {id(c.a), id(c.b), id(c.main), id(c.short)}
         for m in plan.modules():
-            if isinstance(m, (DualInt8Layer, StemLayer)) or (isinstance(m, Int8Layer) and id(m) not in inner):
+            if isinstance(m, (ChainInt8Layer, DualInt8Layer, StemLayer)) or (isinstance(m, Int8Layer) and id(m) not in inner):
                 m.register_forward_hook(lambda mod, args, out: recs.append((mod, args, out)))
         plan(x)
         torch.cuda.synchronize()
-    assert len(recs) == 50, len(recs)       # 1 stem + 45 int8 layers + 4 dual kernels (fusion_report: 54 layers)
+    # 54 layers: 11 chain kernels (2 of them with a convolution shortcut: 24 layers), 2 dual kernels (4), 1 stem, 25 single layers
+    assert len(recs) == 39 and len(chains) == 11, (len(recs), len(chains))
     kinds = set()
     beyond_2g = 0
     for idx, (mod, args, out) in enumerate(recs):
+        if isinstance(mod, ChainInt8Layer):
+            kinds.add(_check_chain_node(mod, args, out, idx))
+            continue
         fp32, codes = out
         emit = mod.a.emit if isinstance(mod, DualInt8Layer) else mod.emit
         o = fp32 if fp32 is not None else codes
@@ -183,6 +190,45 @@ def test_resnet50_batch512_every_plan_node_against_the_oracle():
     print(f"checked {len(recs)} plan nodes x 6 windows; epilogue / kernel kinds seen: {sorted(kinds)}")
 
 
+def _check_chain_node(mod, args, out, idx):
+    """One chain kernel (block end + next block's first 1x1): its fp32 output / codes against the oracle's convolution(s) +
+    shortcut + ReLU, and the second convolution's codes against the oracle's convolution of the FIRST layer's codes (the
+    kernel's own, or the oracle's codes of the kernel's own fp32 output: they never leave the chip otherwise)."""
+    fp32, codes, codes2 = out
+    a, b = mod.a, mod.b
+    n_img, k, P, Q = codes2.shape[0], a.k, codes2.shape[2], codes2.shape[3]
+    for win in _windows(n_img, P, Q):
+        n, p0, q0, ph, qw = win
+        what = f"node {idx} chain {tuple(codes2.shape)} window {win}"
+        if mod.short is None:
+            w_deq, bias, stride, pad = _layer_params(a)
+            ref, mag = _conv_window_ref(args[0], a.act.scale.cpu(), a.act.zp.cpu(), w_deq, bias, stride, pad, win)
+            res = args[1][n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu().double()
+            ref, mag = ref.float().double() + res, mag + res.abs()
+        else:
+            xm, xs = (args[1], args[0]) if mod.swapped else (args[0], args[1])
+            ref = mag = 0
+            for part, xin in ((mod.main, xm), (mod.short, xs)):
+                w_deq, bias, stride, pad = _layer_params(part)
+                one, omag = _conv_window_ref(xin, part.act.scale.cpu(), part.act.zp.cpu(), w_deq, bias, stride, pad, win)
+                ref, mag = ref + one.float().double(), mag + omag
+        ref = torch.relu(ref) if a.relu else ref
+        got32 = None
+        if fp32 is not None:
+            got32 = fp32[n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu()
+            _close(got32, ref, mag, what)
+        if codes is not None:
+            _check_codes(codes[n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu(), got32, ref.float(), a.emit, what)
+        e = a.emit
+        mid = (codes[n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu() if codes is not None else
+               O.fq_zeropoint(got32, e.scale.detach().cpu(), e.zp.detach().cpu(), e.lo, e.hi)[0].to(torch.uint8))
+        w_deq, bias, stride, pad = _layer_params(b)
+        ref2, _ = _conv_window_ref(mid, b.act.scale.cpu(), b.act.zp.cpu(), w_deq, bias, stride, pad, (0, 0, 0, ph, qw))
+        ref2 = torch.relu(ref2) if b.relu else ref2
+        _check_codes(codes2[n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu(), None, ref2.float(), b.emit, what + " second convolution")
+    return f"chain K{k} {'conv shortcut ' if mod.short is not None else ''}{'out ' if fp32 is not None else ''}{'codes' if codes is not None else ''}"
+
+
 def test_byte_offsets_beyond_2_to_the_31():
     """A block-end layer of layer1 (1x1, 64 -> 256 at 56 x 56, shortcut + ReLU + fp32 out + codes) at batch 768: the fp32
     shortcut and output are 2.47 GB each, so the last images lie beyond byte offset 2^31 (and element index 2^29)."""
@@ -233,7 +279,9 @@ def test_fused_plan_teacher_forced_against_the_cpu_port():
     recs = []
     with torch.no_grad():
         net(x)
-        plan = fuse_inference(net)
+        # one node per launch-of-one-layer: the chained plan (block end + next 1x1 in one kernel) is bit-identical to this one
+        # (tests/test_gpu_chain.py) and its chain kernels face the oracle at full size in the test above
+        plan = fuse_inference(net, chain_pairs=False)
         duals = [m for m in plan.modules() if isinstance(m, DualInt8Layer)]
         inner = {id(d.a) for d in duals} | {id(d.b) for d in duals}
         for m in plan.modules():
