@@ -77,7 +77,7 @@ __device__ __forceinline__ void bstore16i(const i32x4& v, int voff, const v4i& r
 }
 template <int CTRL>
 __device__ __forceinline__ float quad_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));   // (every lane reads a live lane: no `old` value to initialise)
 }
 // 4 x 4 transpose across the four lanes of a quad: afterwards x_j of lane b is what x_b of lane j was
 __device__ __forceinline__ void quad_transpose(float& x0, float& x1, float& x2, float& x3, bool b0, bool b1) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
       quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
       f32x4 y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
       if constexpr (!DUALH) y = y + res[P][g];
-      if (ep1.relu) y = f32x4{relu_nan(y.x), relu_nan(y.y), relu_nan(y.z), relu_nan(y.w)};
+      if (ep1.relu) y = relu4_nan(y);
       const int off = fo[g] + n * 256;
       if (a.out) bstore16(y, off, r_out);
       const uint32_t c = eq1.code4(y);
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     for (int g = 0; g < 4; ++g) {
       quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
       f32x4 y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-      if (ep2.relu) y = f32x4{relu_nan(y.x), relu_nan(y.y), relu_nan(y.z), relu_nan(y.w)};
+      if (ep2.relu) y = relu4_nan(y);
       const int lr = wr * 32 + 8 * g + 4 * hsel + b4;
       if (lr < rows_here)
         *reinterpret_cast<uint32_t*>(ep2.codes + (row0 + lr) * KB + wc * (KB / 2) + j * 32 + q4 * 4) = eq2.code4(y);
