@@ -289,6 +289,37 @@ def qbase_backward(x, scale, offset, gy, lo, hi, g):
     return gx, gs
 
 
+def fsptq_act_backward(x, scale, zp, gy, lo, hi):
+    """What autograd executes through FSPTQuant/base.py:108-109 (activations), node by node.
+    Forward: v = x / s; r = ste_round(v); c = clamp(r + zp, lo, hi); y = (c - zp) * s.  Backward of `gy`:
+      mul:   g_c = gy * s                      d/ds += sum(gy * (c - zp))
+      clamp: g_r = where(lo <= r + zp <= hi, g_c, 0)       (ste_round and the additions pass gradients through)
+      div:   g_x = g_r / s                     d/ds += sum(-g_r * (v / s))
+    Returns (g_x, grad_s): g_x bit-exact ((gy * s) / s inside the range, +0 outside), grad_s an fp32 sum."""
+    v = x / scale
+    pre = ste_round(v) + zp
+    c = pre.clamp(lo, hi)
+    inside = (pre >= lo) & (pre <= hi)
+    g_r = torch.where(inside, gy * scale, torch.zeros((), dtype=gy.dtype))
+    gx = g_r / scale
+    gs = (gy * (c - zp)).sum() + (-g_r * (v / scale)).sum()
+    return gx, gs
+
+
+def fsptq_weight_backward(w, scale, gy, lo, hi):
+    """The same through FSPTQuant/base.py:149-152 (weights, per-output-channel scale [K, 1, 1, 1] or [K, 1]):
+    v = w / s; c = clamp(ste_round(v), lo, hi); y = c * s.  Returns (g_w, grad_s[K...]) with grad_s summed per channel."""
+    v = w / scale
+    r = ste_round(v)
+    c = r.clamp(lo, hi)
+    inside = (r >= lo) & (r <= hi)
+    g_r = torch.where(inside, gy * scale, torch.zeros((), dtype=gy.dtype))
+    gw = g_r / scale
+    dims = tuple(range(1, w.dim()))
+    gs = (gy * c).sum(dim=dims, keepdim=True) + (-g_r * (v / scale)).sum(dim=dims, keepdim=True)
+    return gw, gs
+
+
 # --------------------------------------------------------------------------- layer forwards
 def conv_or_linear(layer, x_q, w_q):
     """modules/conv.py:13-19, modules/linear.py:12-13 (and the FSPTQuant/RootQ copies)."""

@@ -390,6 +390,43 @@ def case_fsptq():
             idx += 1
 
 
+def case_fsptq_grad():
+    """Autograd through the FSPTQ live path (FSPTQuant/base.py:108-109,149-152: round_pass STE, clamp masks) with scales shrunk
+    so that part of the data saturates: the specification of the one-pass HIP backward of the ZEROPOINT / SYMMETRIC forms."""
+    for j, ((w_signed, w_bits), (i_signed, i_bits), relu_in) in enumerate((((True, 8), (False, 8), True), ((True, 4), (True, 8), False),
+                                                                            ((True, 8), (False, 8), False))):
+        g = gen(3500 + j)
+        m, x = make_layer("conv", g)
+        x = x * 1.5
+        if relu_in:
+            x = torch.relu(x)          # min == 0: integer zero point (the int8 path's case); otherwise the float minimum
+        qcfg = {"input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": i_bits, "signed": i_signed}},
+                "weight": {"enable": True, "type": "minmax_channel", "recon_type": "None", "args": {"n_bits": w_bits, "signed": w_signed}},
+                "momentum": 0.1}
+        q = fsptq_init(FSPTQuant.FSPTQConv2d, m, qcfg)
+        with torch.no_grad():
+            q.eval()
+            q(x)  # calibrate
+            q.in_scale.mul_(0.6)
+            q.wt_scale.mul_(0.7)
+        cap = Capture(q)
+        xg = x.clone().requires_grad_(True)
+        out = q(xg)
+        gout = torch.randn(out.shape, generator=g)
+        out.backward(gout)
+        name = f"fsptq_grad{j}"
+        extra = {}
+        if isinstance(q.in_scale, torch.nn.Parameter) and q.in_scale.grad is not None:
+            extra["grad_in_scale"] = q.in_scale.grad
+        if isinstance(q.wt_scale, torch.nn.Parameter) and q.wt_scale.grad is not None:
+            extra["grad_wt_scale"] = q.wt_scale.grad
+        put(name, g_fq_input=cap.g_input, g_fq_weight=cap.g_weight, fq_input=cap.input, fq_weight=cap.weight, x=x,
+            weight=m.weight.detach(), bias=m.bias.detach(), gout=gout, in_scale=q.in_scale.detach(),
+            in_offset=q.in_offset.to(torch.float32).reshape(-1), wt_scale=q.wt_scale.detach(), out=out.detach(), grad_x=xg.grad,
+            grad_weight=q.weight.grad, grad_bias=q.bias.grad, **extra)
+        CASES.append(dict(name=name, kind="fsptq_grad", layer="conv", qconfig=qcfg))
+
+
 # ---------------------------------------------------------------------------------- RootQ
 def case_rootq():
     """RootQ/base.py:37-156 + RootQ/function.py:15-32,58-67."""
@@ -584,5 +621,16 @@ def main():
           f"{os.path.getsize(os.path.join(HERE, 'golden_v1.npz')) / 1024:.0f} KiB")
 
 
+def main_supplement():
+    """Cases added after golden_v1 was frozen go to their own pair of files (golden_v1 itself is not regenerated)."""
+    torch.manual_seed(SEED)
+    torch.set_num_threads(1)
+    case_fsptq_grad()
+    np.savez_compressed(os.path.join(HERE, "golden_v1_grad.npz"), **ARR)
+    with open(os.path.join(HERE, "golden_v1_grad.json"), "w") as f:
+        json.dump(dict(seed=SEED, torch=torch.__version__, cases=CASES), f, indent=1, default=str)
+    print(f"{len(CASES)} cases, {len(ARR)} arrays (supplement)")
+
+
 if __name__ == "__main__":
-    main()
+    main_supplement() if "--supplement" in sys.argv else main()

@@ -146,6 +146,25 @@ def test_golden_backward(K, golden):
         torch.testing.assert_close(gs.cpu(), golden.get(c, "grad_wt_scale"), rtol=2e-4, atol=1e-6)
 
 
+def test_golden_backward_fsptq(K, golden):
+    """The one-pass HIP backward of the ZEROPOINT (activations) and SYMMETRIC (per-channel weights) forms against gradients
+    the REFERENCE produced under autograd (tests/golden/golden_v1_grad.*), fed the upstream gradients captured in that run."""
+    from dlmc import _native as n
+    for c in golden.of_kind("fsptq_grad"):
+        ia, wa = c["qconfig"]["input"]["args"], c["qconfig"]["weight"]["args"]
+        (ilo, ihi), (wlo, whi) = O.qrange(ia["signed"], ia["n_bits"]), O.qrange(wa["signed"], wa["n_bits"])
+        x, w = golden.get(c, "x").to(DEV), golden.get(c, "weight").to(DEV)
+        gx, gs = K.fake_quant_backward(x, golden.get(c, "g_fq_input").to(DEV), golden.get(c, "in_scale").to(DEV),
+                                       golden.get(c, "in_offset").to(DEV), ilo, ihi, 0.0, form=n.FORM_ZEROPOINT)
+        assert_bits_equal(gx, golden.get(c, "grad_x"), c["name"] + ".grad_x")
+        torch.testing.assert_close(gs.cpu().reshape(-1), golden.get(c, "grad_in_scale").reshape(-1), rtol=2e-4, atol=1e-6)
+        s_wt = golden.get(c, "wt_scale").to(DEV)
+        gw, gs = K.fake_quant_backward(w, golden.get(c, "g_fq_weight").to(DEV), s_wt.reshape(-1), torch.zeros_like(s_wt).reshape(-1),
+                                       wlo, whi, 0.0, ch_axis=0, form=n.FORM_SYMMETRIC)
+        assert_bits_equal(gw, golden.get(c, "grad_weight"), c["name"] + ".grad_weight")
+        torch.testing.assert_close(gs.cpu().reshape(-1), golden.get(c, "grad_wt_scale").reshape(-1), rtol=2e-4, atol=1e-5)
+
+
 # ------------------------------------------------------------------- seeded inputs vs the oracle
 LAYOUTS = [  # (shape, ch_axis)   ch_axis None = per tensor
     ((4099,), None),                 # numel % 4 != 0

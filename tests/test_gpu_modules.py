@@ -111,6 +111,33 @@ def test_qbase_autograd(golden):
         close(q.wt_scale.grad, golden.get(c, "grad_wt_scale"), c["name"] + ".grad_wt_scale", rtol=2e-3, atol=1e-5)
 
 
+def test_fsptq_autograd(golden):
+    """The FSPTQ wrapper under autograd on the GPU (HIP forward, one-pass HIP backward of both operands) against the gradients
+    the REFERENCE produced on the same inputs with the same (shrunk, partly saturating) scales."""
+    cases = golden.of_kind("fsptq_grad")
+    assert len(cases) == 3
+    for c in cases:
+        net, cap = _quantized(c, golden, "FSPTQ")
+        q = net.layer
+        x = golden.get(c, "x").to(DEV)
+        with torch.no_grad():
+            net.eval()
+            net(x)
+            q.in_scale.copy_(golden.get(c, "in_scale").reshape(q.in_scale.shape))
+            q.wt_scale.copy_(golden.get(c, "wt_scale").reshape(q.wt_scale.shape))
+        xg = x.clone().requires_grad_(True)
+        out = net(xg)
+        assert_bits_equal(cap.input, golden.get(c, "fq_input"), c["name"] + ".fq_input")
+        assert_bits_equal(cap.weight, golden.get(c, "fq_weight"), c["name"] + ".fq_weight")
+        close(out, golden.get(c, "out"), c["name"] + ".out")
+        out.backward(golden.get(c, "gout").to(DEV))
+        close(xg.grad, golden.get(c, "grad_x"), c["name"] + ".grad_x", rtol=1e-3, atol=1e-5)
+        close(q.weight.grad, golden.get(c, "grad_weight"), c["name"] + ".grad_weight", rtol=1e-3, atol=1e-4)
+        close(q.bias.grad, golden.get(c, "grad_bias"), rtol=1e-3, atol=1e-4)
+        close(q.in_scale.grad.reshape(-1), golden.get(c, "grad_in_scale").reshape(-1), c["name"] + ".grad_in_scale", rtol=2e-3, atol=1e-5)
+        close(q.wt_scale.grad.reshape(-1), golden.get(c, "grad_wt_scale").reshape(-1), c["name"] + ".grad_wt_scale", rtol=2e-3, atol=1e-4)
+
+
 def test_fsptq_wrappers(golden):
     from dlmc.quantization.scalar import FSPTQuant
     for c in golden.of_kind("fsptq"):

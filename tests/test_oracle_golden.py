@@ -128,6 +128,28 @@ def test_qbase_backward(golden):
         torch.testing.assert_close(gs_wt.reshape(1), golden.get(c, "grad_wt_scale"), rtol=2e-4, atol=1e-6)
 
 
+def test_fsptq_backward(golden):
+    """FSPTQ's live path under autograd (reference-made gradients, tests/golden/golden_v1_grad.*): the oracle's node-by-node
+    restatement gives the input / weight gradients bit for bit and the scale gradients to summation order."""
+    cases = golden.of_kind("fsptq_grad")
+    assert len(cases) == 3
+    for c in cases:
+        ia, wa = c["qconfig"]["input"]["args"], c["qconfig"]["weight"]["args"]
+        irng, wrng = O.qrange(ia["signed"], ia["n_bits"]), O.qrange(wa["signed"], wa["n_bits"])
+        x, w = golden.get(c, "x"), golden.get(c, "weight")
+        s_in, zp, s_wt = golden.get(c, "in_scale"), golden.get(c, "in_offset"), golden.get(c, "wt_scale")
+        _, xq = O.fq_zeropoint(x, s_in, zp, irng[0], irng[1])
+        _, wq = O.fq_symmetric(w, s_wt, wrng[0], wrng[1])
+        assert_bits_equal(xq, golden.get(c, "fq_input"), c["name"] + ".fq_input")
+        assert_bits_equal(wq, golden.get(c, "fq_weight"), c["name"] + ".fq_weight")
+        gx, gs_in = O.fsptq_act_backward(x, s_in, zp, golden.get(c, "g_fq_input"), irng[0], irng[1])
+        gw, gs_wt = O.fsptq_weight_backward(w, s_wt, golden.get(c, "g_fq_weight"), wrng[0], wrng[1])
+        assert_bits_equal(gx, golden.get(c, "grad_x"), c["name"] + ".grad_x")
+        assert_bits_equal(gw, golden.get(c, "grad_weight"), c["name"] + ".grad_weight")
+        torch.testing.assert_close(gs_in.reshape(-1), golden.get(c, "grad_in_scale").reshape(-1), rtol=2e-4, atol=1e-6)
+        torch.testing.assert_close(gs_wt.reshape(-1), golden.get(c, "grad_wt_scale").reshape(-1), rtol=2e-4, atol=1e-5)
+
+
 def test_funlsq_closed_form(golden):
     for c in golden.of_kind("funlsq"):
         w, s, gout = golden.get(c, "w"), golden.get(c, "scale"), golden.get(c, "gout")
