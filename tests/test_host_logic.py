@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: `quantize_model` (class swap, regex exclusion, per-layer
 overrides, state_dict layout), the benchmark layer tables, and the refusal to run on CPU tensors."""
 import copy
+import os
 import logging
 
 import pytest
@@ -201,3 +202,16 @@ def test_fuse_reports_untraceable_models():
 
     with pytest.raises(RuntimeError, match="torch.fx"):
         fuse_inference(Dyn().eval(), dry_run=True)
+
+
+def test_chain_kernel_listing_has_no_spill_in_its_loop_and_keeps_its_store_wait_states():
+    """tools/lint_chain.py on the cross-compiled listing (hipcc, no GPU): the chain kernel keeps asm-loaded registers in flight
+    across a chunk and counts its own waits, so a spill inside the loop or a missing wait state after an asm store is a bug."""
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "lint_chain.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
