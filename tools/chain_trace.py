@@ -53,7 +53,7 @@ if nc > 4:   # chunks 2 .. nc-2 as one averaged line each
         print(f"  c2..c{nc - 2} {nm:12s} {d[:, cols].mean():8.0f}")
 for j, nm in rows:
     print(f"  {nm:20s} {d[:, j].mean():8.0f} {d[first, j].mean():8.0f} {d[~first, j].mean() if (~first).any() else 0:8.0f}")
-if True:   # fine stamps of chunk 1 (slots 56..60) relative to "c1 ready" (slot 5)
+if int(t[:, 56].max()) > 0:   # fine stamps of chunk 1 (slots 56..60; builds that write them) relative to "c1 ready" (slot 5)
     base = t[:, 5]
     fine = [(t[:, 56 + j] - (base if j == 0 else t[:, 55 + j])).float().mean() for j in range(5)]
     print("  chunk 1 in detail: GEMM 1 retired +%.0f, group 0 +%.0f, group 1 +%.0f, group 2 +%.0f, group 3 +%.0f" % tuple(fine))

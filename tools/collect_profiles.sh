@@ -18,6 +18,9 @@ cd "$GRAFT_REPO_ROOT"
 python3 tools/pmc_summary.py --tail conv_chain_i8_kernel 11 --tail conv_i8_mfma_kernel 27 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
 python3 tools/plan_profile.py resnet50 512 > "$OUT/plan_profile_resnet50_b512.txt" 2>&1
 python3 tools/conv_lab.py --knobs 128:1,64:1,128:0,64:0 > "$OUT/conv_lab_resnet50_layers.txt" 2>&1
+python3 tools/chain_lab.py --rows 64 > "$OUT/chain_lab_resnet50_pairs.txt" 2>&1
+python3 tools/chain_trace.py 512 64 56 256 64 > "$OUT/chain_trace_64_256_64_at_56.txt" 2>&1
+python3 tools/chain_trace.py 512 256 14 1024 256 > "$OUT/chain_trace_256_1024_256_at_14.txt" 2>&1
 python3 tools/conv_trace.py 512 256 14 256 3 > "$OUT/conv_trace_3x3_256_14.txt" 2>&1
 python3 tools/kernel_bench.py > "$OUT/kernel_bench_config2.txt" 2>&1
 python3 tools/run_configs.py > "$OUT/configs_1_3_4_5.json" 2> "$OUT/configs.err"
