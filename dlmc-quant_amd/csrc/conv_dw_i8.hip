@@ -26,19 +26,51 @@ __device__ __forceinline__ f32x4 bytes_s(uint32_t a) {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// 3 x 3, 16 channels per thread (C % 16 == 0): every tap is ONE 16-byte load per lane (the layer is bound by the number of
-// vector-memory instructions through the L1, not by arithmetic: 4-byte taps ran at 0.8 TB/s), all 9 taps and their weights
-// are requested before the first is used; a tap outside the image reads a clamped address and is replaced by the zero point.
-__global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ w,
+// 3 x 3, 16 channels per thread (C % 16 == 0): every tap is ONE 16-byte load per lane, all 9 taps requested before the first
+// is used; a tap outside the image reads a clamped address and is replaced by the zero point.  The first version converted
+// every byte of every tap to fp32 and multiplied there: ~80 vector instructions per output element, 0.73 TB/s - bound by its
+// own arithmetic, not by HBM.  This one stays in integers: the 4 x 4 bytes (4 taps x 4 channels) of four tap dwords are
+// transposed with v_perm_b32 (8 per block) so that a dword holds FOUR TAPS OF ONE CHANNEL, and v_dot4_i32_i8 multiplies it with
+// the channel's four weights (packed once per workgroup into an LDS table, with the channel's constants); unsigned codes are
+// re-centred by xor 0x80 with the constant (128 - zp) * SUM w added back.  Same exact integer sums S1, S0 as before, same fp32
+// chain after them: bit-identical results at a third of the instructions.
+struct DwTab {       // per channel, in LDS: two 16-byte records, each stored [position in the thread's 16 channels][channel group]
+  uint32_t w[3];     // taps 0-3, 4-7, 8 (weights as signed bytes)        so that neighbouring lanes (neighbouring channel groups)
+  int dzw;           // (shift - zp) * SUM w                               read neighbouring records: no bank conflicts
+  float m, mo, b;    // s_in * s_w, s_in * o_w, bias
+  uint32_t pad;
+};
+
+__global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* __restrict__ x, const int8_t* __restrict__ w,
                                                                  float* __restrict__ out, const float* __restrict__ bias,
                                                                  const float* __restrict__ s_in, const float* __restrict__ zp_in,
                                                                  const float* __restrict__ s_w, const float* __restrict__ o_w,
                                                                  DwGeom g, int x_signed, ConvEpi ep) {
-  const int C16 = g.C4 >> 2;
-  const int64_t total = (int64_t)g.N * g.P * g.Q * C16;
+  extern __shared__ __attribute__((aligned(16))) uint8_t dw_lds[];
+  const int C = g.C4 * 4, C16 = g.C4 >> 2;
+  u32x4* tabw = reinterpret_cast<u32x4*>(dw_lds);            // [16][C16]: {w0, w1, w2, dzw}
+  f32x4* tabp = reinterpret_cast<f32x4*>(dw_lds) + C;       // [16][C16]: {m, mo, b, -}
   const float sin = s_in[0], zp = zp_in ? zp_in[0] : 0.0f;
-  const uint32_t zpw = (uint32_t)((int)zp & 0xff) * 0x01010101u;
+  const int zpi = (int)zp;
+  const int dz = (x_signed ? 0 : 128) - zpi;
   const bool asym = o_w != nullptr;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    uint32_t pk[3] = {0u, 0u, 0u};
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int wv = w[k * C + c];
+      sum += wv;
+      pk[k >> 2] |= (uint32_t)(wv & 0xff) << (8 * (k & 3));
+    }
+    const int slot = (c & 15) * C16 + (c >> 4);
+    tabw[slot] = u32x4{pk[0], pk[1], pk[2], (uint32_t)(dz * sum)};
+    tabp[slot] = f32x4{sin * s_w[c], asym ? sin * o_w[c] : 0.0f, bias ? bias[c] : 0.0f, 0.0f};
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)g.N * g.P * g.Q * C16;
+  const uint32_t zpw = (uint32_t)(zpi & 0xff) * 0x01010101u;
+  const uint32_t xw = x_signed ? 0u : 0x80808080u;
   const EpiQuant eq(ep);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t pix = fdiv((uint32_t)i, g.cdiv);                 // (cdiv divides by C / 16 here)
@@ -48,46 +80,71 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
     const uint32_t n = fdiv(t, g.pdiv);
     const int p = (int)(t - n * (uint32_t)g.P);
     const int h0 = p * g.stride - g.pad, w0 = q * g.stride - g.pad;
-    u32x4 a[9], b[9];
+    u32x4 a[9];
     const u32x4* img = x + (int64_t)n * g.H * g.W * C16 + c16;
+    const bool inside = h0 >= 0 && w0 >= 0 && h0 + 2 < g.H && w0 + 2 < g.W;
+    if (__builtin_amdgcn_ballot_w64(!inside) == 0) {      // the whole wave is away from the image border (almost always): no checks
+      const u32x4* p0 = img + ((int64_t)h0 * g.W + w0) * C16;
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int h = h0 + r, ww = w0 + s;
-        const bool ok = h >= 0 && h < g.H && ww >= 0 && ww < g.W;
-        const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = ww < 0 ? 0 : (ww >= g.W ? g.W - 1 : ww);
-        const u32x4 v = img[((int64_t)hc * g.W + wc) * C16];
-        a[r * 3 + s] = ok ? v : u32x4{zpw, zpw, zpw, zpw};
-        b[r * 3 + s] = w[(r * 3 + s) * C16 + c16];
-      }
+        for (int s = 0; s < 3; ++s) a[r * 3 + s] = p0[(r * g.W + s) * C16] ^ xw;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int h = h0 + r, ww = w0 + s;
+          const bool ok = h >= 0 && h < g.H && ww >= 0 && ww < g.W;
+          const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = ww < 0 ? 0 : (ww >= g.W ? g.W - 1 : ww);
+          const u32x4 v = img[((int64_t)hc * g.W + wc) * C16];
+          a[r * 3 + s] = (ok ? v : u32x4{zpw, zpw, zpw, zpw}) ^ xw;   // q' = q - shift as a signed byte
+        }
+    }
     const int c = c16 * 16;
     uint32_t codes[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {                                   // 4 channels at a time
-      f32x4 s1 = {0.0f, 0.0f, 0.0f, 0.0f}, s0 = {0.0f, 0.0f, 0.0f, 0.0f};
+      // bytes of a[k][d]: channels c + 4d .. + 3 of tap k.  Transposed: T[j] = taps 0-3, U[j] = taps 4-7, V[j] = tap 8 of channel j
+      uint32_t T[4], U[4], V[4];
+      {
+        const uint32_t l01 = __builtin_amdgcn_perm(a[1][d], a[0][d], 0x05010400u), h01 = __builtin_amdgcn_perm(a[1][d], a[0][d], 0x07030602u);
+        const uint32_t l23 = __builtin_amdgcn_perm(a[3][d], a[2][d], 0x05010400u), h23 = __builtin_amdgcn_perm(a[3][d], a[2][d], 0x07030602u);
+        T[0] = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
+        T[1] = __builtin_amdgcn_perm(l23, l01, 0x07060302u);
+        T[2] = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
+        T[3] = __builtin_amdgcn_perm(h23, h01, 0x07060302u);
+      }
+      {
+        const uint32_t l01 = __builtin_amdgcn_perm(a[5][d], a[4][d], 0x05010400u), h01 = __builtin_amdgcn_perm(a[5][d], a[4][d], 0x07030602u);
+        const uint32_t l23 = __builtin_amdgcn_perm(a[7][d], a[6][d], 0x05010400u), h23 = __builtin_amdgcn_perm(a[7][d], a[6][d], 0x07030602u);
+        U[0] = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
+        U[1] = __builtin_amdgcn_perm(l23, l01, 0x07060302u);
+        U[2] = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
+        U[3] = __builtin_amdgcn_perm(h23, h01, 0x07060302u);
+      }
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        f32x4 av = x_signed ? bytes_s(a[k][d]) : bytes_u(a[k][d]);
-        const f32x4 bv = bytes_s(b[k][d]);
-        if (zp != 0.0f) av = f32x4{av.x - zp, av.y - zp, av.z - zp, av.w - zp};
-        s1 = f32x4{__builtin_fmaf(av.x, bv.x, s1.x), __builtin_fmaf(av.y, bv.y, s1.y), __builtin_fmaf(av.z, bv.z, s1.z),
-                   __builtin_fmaf(av.w, bv.w, s1.w)};      // exact: integers far below 2^24
-        if (asym) s0 = f32x4{s0.x + av.x, s0.y + av.y, s0.z + av.z, s0.w + av.w};
-      }
-      const int cc = c + d * 4;
-      const f32x4 sw = *reinterpret_cast<const f32x4*>(s_w + cc);
-      f32x4 v = f32x4{s1.x * (sin * sw.x), s1.y * (sin * sw.y), s1.z * (sin * sw.z), s1.w * (sin * sw.w)};
-      if (asym) {
-        const f32x4 ow = *reinterpret_cast<const f32x4*>(o_w + cc);
-        v = f32x4{v.x + s0.x * (sin * ow.x), v.y + s0.y * (sin * ow.y), v.z + s0.z * (sin * ow.z), v.w + s0.w * (sin * ow.w)};
-      }
-      if (bias) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + cc);
-        v = f32x4{v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w};
+      for (int j = 0; j < 4; ++j) V[j] = (a[8][d] >> (8 * j)) & 0xffu;
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 tw = tabw[(d * 4 + j) * C16 + c16];
+        const f32x4 tp = tabp[(d * 4 + j) * C16 + c16];
+        int s1 = __builtin_amdgcn_sdot4((int)T[j], (int)tw.x, (int)tw.w, false);
+        s1 = __builtin_amdgcn_sdot4((int)U[j], (int)tw.y, s1, false);
+        s1 = __builtin_amdgcn_sdot4((int)V[j], (int)tw.z, s1, false);
+        float r = (float)s1 * tp.x;                                  // S1 = SUM (q - zp) * qw, exact
+        if (asym) {
+          int s0 = __builtin_amdgcn_sdot4((int)T[j], 0x01010101, 9 * dz, false);
+          s0 = __builtin_amdgcn_sdot4((int)U[j], 0x01010101, s0, false);
+          s0 = __builtin_amdgcn_sdot4((int)V[j], 0x01010101, s0, false);
+          r = r + (float)s0 * tp.y;                                  // S0 = SUM (q - zp)
+        }
+        if (bias) r = r + tp.z;
+        v[j] = r;
       }
       if (ep.relu) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
-      const int64_t at = (int64_t)pix * g.C4 * 4 + cc;
+      const int64_t at = (int64_t)pix * g.C4 * 4 + c + d * 4;
       if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
       if (ep.codes) codes[d] = eq.code4(v);
     }
@@ -187,13 +244,14 @@ extern "C" int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* ou
   const int64_t total = N * P * Q * (C / 4);
   const int64_t blocks = (total + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool wide = R == 3 && S == 3 && C % 16 == 0 && aligned16(x) && aligned16(w) && (!codes || aligned16(codes));
+  const bool wide = R == 3 && S == 3 && C % 16 == 0 && C <= 2048 && aligned16(x) && (!codes || aligned16(codes));
   if (wide) {
     g.cdiv = make_fastdiv((uint32_t)(C / 16));
     const int64_t b16 = (N * P * Q * (C / 16) + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
-    hipLaunchKernelGGL(conv_dw3_i8_kernel, dim3((uint32_t)(b16 < (1 << 20) ? b16 : (1 << 20))), dim3(DLMCQ_BLOCK), 0, st,
-                       static_cast<const u32x4*>(x), reinterpret_cast<const u32x4*>(w), out, bias, in_scale, in_zero_point, w_scale,
-                       w_offset, g, x_is_unsigned ? 0 : 1, ep);
+    // every workgroup packs the layer's weights into its LDS table first: a grid of a few workgroups per CU, each walking many pixels
+    hipLaunchKernelGGL(conv_dw3_i8_kernel, dim3((uint32_t)(b16 < 4096 ? b16 : 4096)), dim3(DLMCQ_BLOCK), (size_t)C * sizeof(DwTab), st,
+                       static_cast<const u32x4*>(x), w, out, bias, in_scale, in_zero_point, w_scale, w_offset, g,
+                       x_is_unsigned ? 0 : 1, ep);
   } else {
     hipLaunchKernelGGL(conv_dw_i8_kernel, dim3((uint32_t)(blocks < (1 << 20) ? blocks : (1 << 20))), dim3(DLMCQ_BLOCK), 0, st,
                        static_cast<const uint32_t*>(x), reinterpret_cast<const uint32_t*>(w), out, bias, in_scale, in_zero_point, w_scale,
