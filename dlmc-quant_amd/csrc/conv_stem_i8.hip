@@ -89,6 +89,7 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void quantize_weight_stem_kernel(const
 // ----------------------------------------------------------------------------- the convolution
 struct StemGeom {
   int N, Hp, Wp, K, R, stride, P, Q;
+  int S, C;      // filter width and real input channels (ASYM only: which operand bytes count towards SUM x')
   int64_t M;     // N*P*Q
   int ntiles;    // ceil(M / 32)
   FastDiv qdiv, pdiv;
@@ -99,7 +100,10 @@ constexpr int ST_EP_LD = 68;   // floats per staged row (64 + 4 pad)
 
 // One wave = one 32-pixel x 64-channel output tile at a time (grid-stride over tiles); 4 independent waves per
 // workgroup.  blockIdx.y selects the 64-channel slab.
-template <int R>
+// ASYM: asymmetric per-channel weights w' = qw * s_w[k] + o_w[k] (ops.py:129-136; ep.w_off): the extra term o_w[k] * SUM x' of the
+// receptive field, SUM x' = s_in * (SUM q' + (shift - zp) * R * S * C), the code sum taken from the operand fragments with
+// v_dot4_i32_i8 against a 0/1 mask of the bytes that are real taps and real channels (as in conv_i8.hip's ASYM instantiation).
+template <int R, bool ASYM = false>
 __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                            float* __restrict__ out, const float* __restrict__ bias,
                                                            const int32_t* __restrict__ wsum, const float* __restrict__ s_in,
@@ -137,6 +141,19 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
   float* stg = stage + wave * (32 * ST_EP_LD);
   const int er = lane >> 4, ec = (lane & 15) * 4;
   const int rowbytes = g.Wp * 4;
+  __shared__ int s0tab[ASYM ? 4 * 32 : 1];
+  float woff[2] = {0.0f, 0.0f};
+  int maskw[4] = {0, 0, 0, 0};
+  if (ASYM) {
+    const int cm = g.C >= 4 ? 0x01010101 : (g.C == 3 ? 0x00010101 : (g.C == 2 ? 0x00000101 : 0x00000001));
+#pragma unroll
+    for (int d = 0; d < 4; ++d) maskw[d] = (hsel * 4 + d < g.S) ? cm : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = n0 + j * 32 + (lane & 31);
+      woff[j] = k < g.K ? sin * ep.w_off[k] : 0.0f;
+    }
+  }
 
   for (int tile = blockIdx.x * 4 + wave; tile < g.ntiles; tile += gridDim.x * 4) {
     const int64_t m0 = (int64_t)tile * 32;
@@ -155,11 +172,27 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[j][i] = 0;
+    int s0 = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const i32x4 a = i32x4{(int)(af[r].x ^ xorw), (int)(af[r].y ^ xorw), (int)(af[r].z ^ xorw), (int)(af[r].w ^ xorw)};
+      if (ASYM) {
+        s0 = __builtin_amdgcn_sdot4(a.x, maskw[0], s0, false);
+        s0 = __builtin_amdgcn_sdot4(a.y, maskw[1], s0, false);
+        s0 = __builtin_amdgcn_sdot4(a.z, maskw[2], s0, false);
+        s0 = __builtin_amdgcn_sdot4(a.w, maskw[3], s0, false);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[r][j], acc[j], 0, 0, 0);
+    }
+    float s0r[ASYM ? 16 : 1];
+    if (ASYM) {      // lanes p and p + 32 hold the two tap halves of pixel p; the sums go through LDS into the accumulator layout
+      s0 += __shfl_xor(s0, 32, 64);
+      s0 += (shift - zpi) * (R * g.S * g.C);
+      if (hsel == 0) s0tab[wave * 32 + (lane & 31)] = s0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (a wave reads only its own 32 sums)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s0r[ASYM ? i : 0] = (float)s0tab[wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hsel];
     }
     // ---- epilogue: accumulator layout (lane = channel, register = pixel) -> pixel-major through this wave's stage ----
 #pragma unroll
@@ -167,7 +200,9 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = (i & 3) + 8 * (i >> 2) + 4 * hsel;
-        stg[r * ST_EP_LD + j * 32 + (lane & 31)] = (float)(acc[j][i] + corr[j]) * mult[j] + bv[j];
+        float v = (float)(acc[j][i] + corr[j]) * mult[j] + bv[j];
+        if (ASYM) v = v + s0r[ASYM ? i : 0] * woff[j];
+        stg[r * ST_EP_LD + j * 32 + (lane & 31)] = v;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave reads back only what it wrote itself
     const int col = n0 + ec;
@@ -460,12 +495,11 @@ extern "C" int dlmcq_quantize_weight_stem_i8(const float* w, int8_t* wq, int32_t
   return launch_status();
 }
 
-extern "C" int dlmcq_conv2d_i8_stem_fused(const void* xpad, const int8_t* w, float* out, const float* bias,
-                                          const int32_t* wsum, const float* in_scale, const float* in_zero_point,
-                                          const float* w_scale, int64_t N, int64_t Hp, int64_t Wp, int64_t K, int64_t R,
-                                          int64_t S, int32_t stride, int32_t x_is_unsigned, int32_t relu, void* codes,
-                                          const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
-                                          int32_t q_form, float q_ste_g, dlmcq_stream_t stream) {
+static int stem_launch(const void* xpad, const int8_t* w, float* out, const float* bias, const int32_t* wsum, const float* in_scale,
+                       const float* in_zero_point, const float* w_scale, const float* w_offset, int64_t C, int64_t N, int64_t Hp,
+                       int64_t Wp, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t x_is_unsigned, int32_t relu, void* codes,
+                       const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi, int32_t q_form, float q_ste_g,
+                       dlmcq_stream_t stream) {
   if (N < 0 || Hp < 1 || Wp < 1 || K < 1 || R < 1 || R > ST_MAXR || S < 1 || S > 8 || stride < 1) return DLMCQ_EINVAL;
   if (Hp < R || Wp < S || (K & 3)) return DLMCQ_EINVAL;
   const int64_t P = (Hp - R) / stride + 1, Q = (Wp - S) / stride + 1;
@@ -479,11 +513,13 @@ extern "C" int dlmcq_conv2d_i8_stem_fused(const void* xpad, const int8_t* w, flo
   if (M >= (1ll << 31) || N * Hp * Wp >= (1ll << 31)) return DLMCQ_ERANGE;
   StemGeom g;
   g.N = (int)N; g.Hp = (int)Hp; g.Wp = (int)Wp; g.K = (int)K; g.R = (int)R; g.stride = stride; g.P = (int)P; g.Q = (int)Q;
+  g.S = (int)S; g.C = (int)C;
   g.M = M;
   g.ntiles = (int)((M + 31) / 32);
   g.qdiv = make_fastdiv((uint32_t)Q);
   g.pdiv = make_fastdiv((uint32_t)P);
   ConvEpi ep{};
+  ep.w_off = w_offset;
   ep.relu = relu != 0;
   ep.codes = static_cast<uint8_t*>(codes);
   ep.q_scale = q_scale;
@@ -498,17 +534,42 @@ extern "C" int dlmcq_conv2d_i8_stem_fused(const void* xpad, const int8_t* w, flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint8_t* xs = static_cast<const uint8_t*>(xpad);
 #define DLMCQ_STEM_ARGS grid, dim3(256), 0, st, xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep
+#define DLMCQ_STEM_CASE(RR) \
+  case RR:                  \
+    if (w_offset) hipLaunchKernelGGL((conv_stem_i8_kernel<RR, true>), DLMCQ_STEM_ARGS); \
+    else hipLaunchKernelGGL((conv_stem_i8_kernel<RR, false>), DLMCQ_STEM_ARGS);         \
+    break;
   switch ((int)R) {
-    case 1: hipLaunchKernelGGL((conv_stem_i8_kernel<1>), DLMCQ_STEM_ARGS); break;
-    case 2: hipLaunchKernelGGL((conv_stem_i8_kernel<2>), DLMCQ_STEM_ARGS); break;
-    case 3: hipLaunchKernelGGL((conv_stem_i8_kernel<3>), DLMCQ_STEM_ARGS); break;
-    case 4: hipLaunchKernelGGL((conv_stem_i8_kernel<4>), DLMCQ_STEM_ARGS); break;
-    case 5: hipLaunchKernelGGL((conv_stem_i8_kernel<5>), DLMCQ_STEM_ARGS); break;
-    case 6: hipLaunchKernelGGL((conv_stem_i8_kernel<6>), DLMCQ_STEM_ARGS); break;
-    default: hipLaunchKernelGGL((conv_stem_i8_kernel<7>), DLMCQ_STEM_ARGS); break;
+    DLMCQ_STEM_CASE(1) DLMCQ_STEM_CASE(2) DLMCQ_STEM_CASE(3) DLMCQ_STEM_CASE(4) DLMCQ_STEM_CASE(5) DLMCQ_STEM_CASE(6)
+    default:
+      if (w_offset) hipLaunchKernelGGL((conv_stem_i8_kernel<7, true>), DLMCQ_STEM_ARGS);
+      else hipLaunchKernelGGL((conv_stem_i8_kernel<7, false>), DLMCQ_STEM_ARGS);
+      break;
   }
+#undef DLMCQ_STEM_CASE
 #undef DLMCQ_STEM_ARGS
   return launch_status();
+}
+
+extern "C" int dlmcq_conv2d_i8_stem_fused(const void* xpad, const int8_t* w, float* out, const float* bias,
+                                          const int32_t* wsum, const float* in_scale, const float* in_zero_point,
+                                          const float* w_scale, int64_t N, int64_t Hp, int64_t Wp, int64_t K, int64_t R,
+                                          int64_t S, int32_t stride, int32_t x_is_unsigned, int32_t relu, void* codes,
+                                          const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
+                                          int32_t q_form, float q_ste_g, dlmcq_stream_t stream) {
+  return stem_launch(xpad, w, out, bias, wsum, in_scale, in_zero_point, w_scale, nullptr, 4, N, Hp, Wp, K, R, S, stride,
+                     x_is_unsigned, relu, codes, q_scale, q_zero_point, q_lo, q_hi, q_form, q_ste_g, stream);
+}
+
+extern "C" int dlmcq_conv2d_i8_stem_asym(const void* xpad, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                                         const float* in_scale, const float* in_zero_point, const float* w_scale,
+                                         const float* w_offset, int64_t C, int64_t N, int64_t Hp, int64_t Wp, int64_t K, int64_t R,
+                                         int64_t S, int32_t stride, int32_t x_is_unsigned, int32_t relu, void* codes,
+                                         const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
+                                         int32_t q_form, float q_ste_g, dlmcq_stream_t stream) {
+  if (!w_offset || C < 1 || C > 4) return DLMCQ_EINVAL;
+  return stem_launch(xpad, w, out, bias, wsum, in_scale, in_zero_point, w_scale, w_offset, C, N, Hp, Wp, K, R, S, stride,
+                     x_is_unsigned, relu, codes, q_scale, q_zero_point, q_lo, q_hi, q_form, q_ste_g, stream);
 }
 
 extern "C" int dlmcq_maxpool_codes_nhwc(const void* x, void* y, int64_t N, int64_t H, int64_t W, int64_t C, int32_t kernel,

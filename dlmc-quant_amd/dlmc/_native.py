@@ -74,6 +74,8 @@ SIGNATURES = {
     "dlmcq_quantize_weight_stem_i8": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i32, _p]),
     "dlmcq_conv2d_i8_stem_fused": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32,
                                                  _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
+    "dlmcq_conv2d_i8_stem_asym": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32,
+                                                _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
     "dlmcq_conv2d_i8_stem_pool_fused": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32,
                                                       _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
     "dlmcq_maxpool_codes_nhwc": (ctypes.c_int, [_p, _p, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p]),

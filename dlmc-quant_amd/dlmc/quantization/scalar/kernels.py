@@ -684,10 +684,12 @@ def quantize_weight_stem(w, scale, lo, hi):
     return wq, wsum
 
 
-def conv2d_i8_stem(xpad, wq, wsum, bias, in_scale, in_zp, w_scale, S, stride=1, relu=False, emit=None, want_out=True, pool=False):
+def conv2d_i8_stem(xpad, wq, wsum, bias, in_scale, in_zp, w_scale, S, stride=1, relu=False, emit=None, want_out=True, pool=False,
+                   w_offset=None, channels=4):
     """The first-layer convolution on padded NHWC4 codes (quantize_pad_nhwc4 / quantize_weight_stem).  Returns fp32
     (N, K, P, Q) channels_last, or `(out, codes)` with `emit` (see conv2d_i8).  `pool=True` (K <= 64): followed by
-    MaxPool2d(3, 2, 1) in the same kernel - the results are the pooled tensors."""
+    MaxPool2d(3, 2, 1) in the same kernel - the results are the pooled tensors.  `w_offset` ([K] fp32, with the image's real
+    channel count `channels`): asymmetric per-channel weights (dlmcq_conv2d_i8_stem_asym; not with `pool`)."""
     N.require_gpu(xpad, wq)
     n, hp, wp, _ = xpad.shape
     K_, R = wq.shape[0], wq.shape[1]
@@ -717,6 +719,16 @@ def conv2d_i8_stem(xpad, wq, wsum, bias, in_scale, in_zp, w_scale, S, stride=1, 
         q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, xpad).reshape(-1)
         lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
     oe = n * K_ * P * Q
+    if w_offset is not None:
+        if pool:
+            raise ValueError("conv2d_i8_stem: the pooling kernel has no weight-offset term")
+        w_offset = _f32c(w_offset.detach(), xpad).reshape(-1)
+        PROFILE.launch("conv_stem", xpad.numel() + wq.numel() + oe * (4 * want_out + (emit is not None)),
+                       lambda: N.check(N.lib.dlmcq_conv2d_i8_stem_asym(
+                           N.ptr(xpad), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),
+                           N.ptr(w_offset), int(channels), n, hp, wp, K_, R, int(S), int(stride), int(xpad.dtype == torch.uint8),
+                           int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())))
+        return (out, out_codes) if emit is not None else out
     PROFILE.launch("conv_stem", xpad.numel() + wq.numel() + oe * (4 * want_out + (emit is not None)),
                    lambda: N.check((N.lib.dlmcq_conv2d_i8_stem_pool_fused if pool else N.lib.dlmcq_conv2d_i8_stem_fused)(
                        N.ptr(xpad), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),

@@ -92,8 +92,6 @@ def _frozen_spec(mod):
         return None
     if len(spec) == 4:
         spec = spec + (None, None)
-    if kind == "stem" and spec[4] is not None:
-        return None                       # (the first-layer kernel has no weight-offset term)
     return spec[:4] + (kind,) + spec[4:]
 
 
@@ -467,7 +465,15 @@ class StemLayer(_PlanLayer):
 
     def __init__(self, layer, spec, **kw):
         super().__init__(layer, spec, **kw)
-        wq, wsum = K.quantize_weight_stem(layer.weight, self.w_scale, self.w_lo, self.w_hi)
+        self.c = layer.weight.shape[1]
+        if self._w_codes is None:
+            wq, wsum = K.quantize_weight_stem(layer.weight, self.w_scale, self.w_lo, self.w_hi)
+        else:     # the module's own integer codes (asymmetric / per-channel QBase weights) in the stem kernel's [K, R, 8 taps, 4] layout
+            q = _weight_codes(self)                                                # [K, C, R, S] int16, re-centred
+            k, c, r, s_ = q.shape
+            full = torch.zeros((k, r, 8, 4), dtype=torch.int16, device=q.device)
+            full[:, :, :s_, :c] = q.permute(0, 2, 3, 1)
+            wq, wsum = full.to(torch.int8).contiguous(), q.sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
         self.register_buffer("wq", wq, persistent=False)
         self.register_buffer("wsum", wsum, persistent=False)
 
@@ -477,10 +483,10 @@ class StemLayer(_PlanLayer):
         pad, st = lay.padding[0], lay.stride[0]
         k, _, r, s = lay.weight.shape
         emit = self._emit_for(x.shape[0], k, (x.shape[2] + 2 * pad - r) // st + 1, (x.shape[3] + 2 * pad - s) // st + 1)
-        in_kernel = self.pool == (3, 2, 1) and k <= 64      # conv + ReLU + MaxPool2d(3, 2, 1) + quantiser: one kernel
+        in_kernel = self.pool == (3, 2, 1) and k <= 64 and self.w_off is None      # conv + ReLU + MaxPool2d(3, 2, 1) + quantiser: one kernel
         xpad = K.quantize_pad_nhwc4(x, act.scale, act.zp, act.lo, act.hi, act.form, pad, g=act.g(numel))
         res = K.conv2d_i8_stem(xpad, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale, s, stride=st,
-                               relu=self.relu, emit=emit, want_out=self.want_out, pool=in_kernel)
+                               relu=self.relu, emit=emit, want_out=self.want_out, pool=in_kernel, w_offset=self.w_off, channels=self.c)
         out, out_codes = res if emit is not None else (res, None)
         return (out, out_codes) if in_kernel else self._finish(out, out_codes)
 
@@ -617,7 +623,8 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True):
             cons = [accepts(u, mp) for u in mp.users]
             on_codes = cons and all(c is not None for c in cons) and len({c.key for c in cons}) == 1
             # the first-layer kernel pools in fp32 itself (any consumers); elsewhere the pool runs on the emitted codes
-            in_stem = spec[4] == "stem" and _pool_params(mp, modules) == (3, 2, 1) and modules[node.target].weight.shape[0] <= 64
+            in_stem = (spec[4] == "stem" and _pool_params(mp, modules) == (3, 2, 1) and modules[node.target].weight.shape[0] <= 64 and
+                       spec[5] is None)       # (the pooling first-layer kernel has no weight-offset term)
             if on_codes or in_stem:
                 pool = _pool_params(mp, modules)
                 chain.append(mp)

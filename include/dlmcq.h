@@ -452,6 +452,15 @@ int dlmcq_conv2d_i8_stem_fused(const void* xpad, const int8_t* w, float* out, co
                                const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
                                int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
 
+/* dlmcq_conv2d_i8_stem_fused for ASYMMETRIC per-output-channel weights (as dlmcq_conv2d_i8_nhwc_asym: w' = qw * s_w[k] + o_w[k]):
+ * the term o_w[k] * SUM x' comes from a per-pixel sum of the operand codes over the R x S taps and the C real channels
+ * (C <= 4: the 4th byte of a pixel and the taps beyond S are excluded by a 0/1 byte mask). */
+int dlmcq_conv2d_i8_stem_asym(const void* xpad, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                              const float* in_scale, const float* in_zero_point, const float* w_scale, const float* w_offset,
+                              int64_t C, int64_t N, int64_t Hp, int64_t Wp, int64_t K, int64_t R, int64_t S, int32_t stride,
+                              int32_t x_is_unsigned, int32_t relu, void* codes, const float* q_scale, const float* q_zero_point,
+                              int32_t q_lo, int32_t q_hi, int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
+
 /*
  * dlmcq_conv2d_i8_stem_fused followed by ReLU (if asked) and nn.MaxPool2d(3, 2, 1) in ONE kernel, K <= 64: out / codes
  * are the POOLED tensor [N, (P+1)/2.., (Q+1)/2.., K].  The pool runs on the fp32 values (the reference's order: ReLU,

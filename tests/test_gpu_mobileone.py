@@ -76,7 +76,7 @@ W8A8_FSPTQ = {  # example/quantization/FSPTQ_config.yaml:40-53 (symmetric per-ch
 @pytest.mark.parametrize("family,batch,size,full", [(None, 3, 64, True), (None, 64, 224, False), ("FSPTQ", 3, 64, True)])
 def test_mobileone_s1_w4a8_plan_node_by_node(family, batch, size, full):
     import workloads as W
-    from dlmc.utils.fuse import DwInt8Layer, Int8Layer, fuse_inference
+    from dlmc.utils.fuse import DwInt8Layer, Int8Layer, StemLayer, fuse_inference
     from dlmc.utils.quantize import quantize_model
     torch.manual_seed(2333)
     net = W.mobileone_s1_deploy().to(DEV).eval()
@@ -88,12 +88,13 @@ def test_mobileone_s1_w4a8_plan_node_by_node(family, batch, size, full):
         plan = fuse_inference(net)
         rep = plan.fusion_report
         for m in plan.modules():
-            if isinstance(m, Int8Layer):
+            if isinstance(m, (Int8Layer, StemLayer)):
                 m.register_forward_hook(lambda mod, args, out: recs.append((mod, args, out)))
         got = plan(x)
     n_dw = sum(isinstance(r[0], DwInt8Layer) for r in recs)
-    assert n_dw == 21 and len(recs) == 21 + 21 + 1, (n_dw, len(recs), rep)     # 21 units + the classifier; the stem is below
-    assert rep.skipped in ([], ["stage0.0"]), rep
+    # the 3-channel first layer (matrix cores, with the weight-offset term for the asymmetric W4 weights), 21 units, the classifier
+    assert n_dw == 21 and len(recs) == 1 + 21 + 21 + 1 and isinstance(recs[0][0], StemLayer), (n_dw, len(recs), rep)
+    assert rep.skipped == [] and rep.stem == 1, rep
     for idx, (mod, args, out) in enumerate(recs):
         if mod.layer.weight.dim() == 2:
             continue                         # the classifier reads fp32 features: checked through the logits below
@@ -130,3 +131,31 @@ def test_depthwise_kernel_shapes_and_forms():
         close(out.cpu(), ref, mag, f"dw case {idx}")
         from oracle import fakequant_oracle as O
         assert torch.equal(oc.cpu().float(), O.fq_zeropoint(out.cpu(), emit.scale.cpu(), emit.zero_point.cpu(), 0, 255)[0]), f"dw case {idx} codes"
+
+
+@pytest.mark.parametrize("c,k,r,stride,pad", [(3, 64, 3, 2, 1), (1, 32, 5, 1, 2), (4, 96, 7, 2, 3), (2, 8, 1, 1, 0)])
+def test_asymmetric_first_layer_kernel(c, k, r, stride, pad):
+    """dlmcq_conv2d_i8_stem_asym alone: every channel count the padded NHWC4 buffer allows, taps up to 7, against the float64
+    convolution of (q - zp) * s_in with w' = qw * s_w + o_w (the operand-sum term must skip the 4th byte and the taps beyond S)."""
+    import torch.nn.functional as F
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator().manual_seed(c * 100 + k)
+    n, h = 3, 19
+    x = torch.relu(torch.randn(n, c, h, h, generator=g))
+    s_in, zp = torch.tensor([float(x.max()) / 255]), torch.tensor([0.0])
+    qw = torch.randint(0, 16, (k, c, r, r), generator=g)
+    s_w, o_w = torch.rand(k, generator=g) * 0.05 + 0.01, -torch.rand(k, generator=g) * 0.3
+    bias = torch.randn(k, generator=g)
+    xpad = K.quantize_pad_nhwc4(x.to(DEV), s_in.to(DEV), zp.to(DEV), 0, 255, N.FORM_ZEROPOINT, pad)
+    full = torch.zeros(k, r, 8, 4, dtype=torch.int8)
+    full[:, :, :r, :c] = qw.permute(0, 2, 3, 1).to(torch.int8)
+    wsum = qw.sum(dim=(1, 2, 3)).to(torch.int32)
+    out = K.conv2d_i8_stem(xpad, full.to(DEV), wsum.to(DEV), bias.to(DEV), s_in.to(DEV), zp.to(DEV), s_w.to(DEV), r, stride=stride,
+                           relu=False, w_offset=o_w.to(DEV), channels=c)
+    codes = torch.clamp(torch.round(x / s_in), 0, 255)
+    xd = (codes.double() - 0.0) * float(s_in)
+    wd = qw.double() * s_w.double().reshape(-1, 1, 1, 1) + o_w.double().reshape(-1, 1, 1, 1)
+    ref = F.conv2d(xd, wd, bias.double(), stride=stride, padding=pad)
+    mag = F.conv2d(xd.abs(), wd.abs(), bias.double().abs(), stride=stride, padding=pad)
+    close(out.cpu(), ref, mag, f"asym stem c={c} k={k} r={r}")

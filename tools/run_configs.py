@@ -123,7 +123,7 @@ def main():
     # ---- config 5
     # W4A8, asymmetric per-channel weights (QBase family): the reference's own op sequence (fp32 convolutions of the
     # fake-quantised operands, module by module) and the frozen plan (depthwise layers on conv_dw_i8.hip, pointwise layers on the
-    # matrix cores with the weight-offset term, 96-channel tensors padded to 128; the 3-channel first layer stays fp32)
+    # matrix cores with the weight-offset term, 96-channel tensors padded to 128; the 3-channel first layer on conv_stem_i8.hip's ASYM instantiation)
     for mode in ("fp32conv_modules", "fused_plan"):
         m = W.mobileone_s1_deploy().to(DEV).eval()
         quantize_model(m, cfg("minmax_channel", 4, False, 8, False, False), None)
