@@ -52,6 +52,8 @@ __device__ __forceinline__ f32x4 relu4_nan(const f32x4& y) {
 }
 
 struct EpiQuant {   // the consumer's constants, resolved once per thread
+  // |t - tie| must reach this for the fast path to stand (see code4_fast: the bound on |t - (d + zadd)| is 1.75 * 2^-14)
+  static constexpr float TIE_THR = 0.5f - 0x1p-13f;
   float dv, rdv, of, zadd, lo, hi;
   float lo_fast;    // lower clamp of the fast path: `lo`, or max(lo, code of 0) when the ReLU is folded into the quantiser
   int form;
@@ -88,24 +90,40 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
     return clamp_nan(ste_round(v / dv), lo, hi);
   }
   __device__ __forceinline__ uint32_t exact(float v) const { return (uint32_t)(code_of(exact_q(v)) & 0xff); }
-  // four of them, as a loop (one copy of the division per call site: the kernels inline code4 many times)
-  __device__ __forceinline__ uint32_t exact4(const f32x4& v) const {
-    uint32_t w = 0;
+  // The rare path of code4: `wfast` holds the fast path's bytes, of which at least one failed its tie test in this lane.
+  // Only the failing ELEMENTS are redone (the test is repeated per element; an element that passes keeps its fast byte,
+  // which the argument below vouches for element by element), and the exact division exists once, in a loop over the set
+  // bits of the lane's failure mask: a wave that enters here typically has ONE failing element in one lane, so it pays one
+  // division instead of the four per lane of rounds 1-2a (which were ~5 of the ~23 vector instructions an output element
+  // cost on average).
+  __device__ __forceinline__ uint32_t exact4(const f32x4& v, uint32_t wfast) const {
+    const float t0 = __builtin_fmaf(v.x - of, rdv, zadd), t1 = __builtin_fmaf(v.y - of, rdv, zadd);
+    const float t2 = __builtin_fmaf(v.z - of, rdv, zadd), t3 = __builtin_fmaf(v.w - of, rdv, zadd);
+    uint32_t m = (!(__builtin_fabsf(t0 - __builtin_rintf(t0)) < TIE_THR) ? 1u : 0u) |
+                 (!(__builtin_fabsf(t1 - __builtin_rintf(t1)) < TIE_THR) ? 2u : 0u) |
+                 (!(__builtin_fabsf(t2 - __builtin_rintf(t2)) < TIE_THR) ? 4u : 0u) |
+                 (!(__builtin_fabsf(t3 - __builtin_rintf(t3)) < TIE_THR) ? 8u : 0u);
+    uint32_t w = wfast;
 #pragma unroll 1
-    for (int e = 0; e < 4; ++e) {
+    while (m) {
+      const int e = __builtin_ctz(m);
+      m &= m - 1u;
       float u = e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
       if (fold) u = relu_nan(u);
-      w |= exact(u) << (8 * e);
+      const int sh = 8 * e;
+      w = (w & ~(0xffu << sh)) | (exact(u) << sh);
     }
     return w;
   }
   // For a FINITE quotient d = fl(u / dv), u = v - of, all four forms reduce to  code = clamp(rint(d) + zadd, lo, hi)
   // (rint(clamp(d)) = clamp(rint(d)) for integral bounds; the STE identity (r - d) + d returns r exactly).
   // A correctly rounded division costs ~25 VALU operations per element - more than everything else in the epilogue -
-  // so d is replaced by t = fl(u * fl(1/dv)), which differs from d by less than 2^-22 |t|.  For |t| <= 512 that is
-  // below 2^-13: unless t lies within 2^-12 of a rounding tie (x.5), rint(t) = rint(d); for |t| > 512 both saturate
-  // to the same bound (|zadd| <= 256, |lo|, |hi| <= 255).  Ties that close, infinities and NaNs (about one element in
-  // 2000) take the exact division, four elements at a time.  Bit-identical codes at ~6 operations per element: the
+  // so d is replaced by t = fl(u * fl(1/dv) + zadd) (one fma).  With q = u/dv: |u fl(1/dv) - q| <= 2^-24 |q|, the fma rounds by
+  // <= 2^-24 |t|, and |d - q| <= 2^-24 |q|, so |t - (d + zadd)| <= 2^-23 |q| + 2^-24 |t|.  A code that does not saturate has
+  // |q| <= 512 and |t| <= 768 (|zadd| <= 256, |lo|, |hi| <= 255): the difference is below 1.75 * 2^-14 < 2^-13, so unless t lies
+  // within 2^-13 of a rounding tie (x.5), rint(t) = rint(d) + zadd; beyond that range both saturate to the same bound.  Ties
+  // that close, infinities and NaNs (about one element in 4000) take the exact division, element by element (exact4).
+  // Bit-identical codes at ~6 operations per element: the
   // block-end layers are bound by the VALU instructions of their epilogue (tools/chain_trace.py), so the arithmetic
   // is written on pairs (v_pk_add_f32 / v_pk_mul_f32: two elements per instruction, same roundings), and a non-finite
   // t needs no separate test: t - rint(t) is NaN then, and NaN is "not below the threshold".
@@ -113,8 +131,7 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
   // Callers with several independent quads evaluate them all, OR the flags and branch ONCE: a branch per quad chains
   // the quads one behind the other (each ~25 dependent instructions long), which is what bounded the block-end layers.
   // The zero point rides on the multiply: t = fma(u, 1/dv, zadd) (zadd is integral, checked above), q = rint(t).  t differs
-  // from u/dv + zadd by less than 2^-22 |u/dv| + 2^-24 |t| < 2^-12 in the range that does not saturate, so the argument above
-  // carries over with the tie test applied to t itself: 6 instructions per element (fma, rint, sub, compare, clamp, pack)
+  // from d + zadd by less than 2^-13 in the range that does not saturate (above), so the tie test is applied to t itself: 6 instructions per element (fma, rint, sub, compare, clamp, pack)
   // when the form has no offset to subtract first (OFZ).
   template <bool OFZ>
   __device__ __forceinline__ uint32_t code4_fast(const f32x4& v, bool& unsure) const {
@@ -122,7 +139,7 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
     const float t0 = __builtin_fmaf(u0, rdv, zadd), t1 = __builtin_fmaf(u1, rdv, zadd), t2 = __builtin_fmaf(u2, rdv, zadd),
                 t3 = __builtin_fmaf(u3, rdv, zadd);
     const float r0 = __builtin_rintf(t0), r1 = __builtin_rintf(t1), r2 = __builtin_rintf(t2), r3 = __builtin_rintf(t3);
-    constexpr float thr = 0.5f - 0x1p-12f;
+    constexpr float thr = TIE_THR;
     unsure = !(__builtin_fabsf(t0 - r0) < thr) | !(__builtin_fabsf(t1 - r1) < thr) | !(__builtin_fabsf(t2 - r2) < thr) |
              !(__builtin_fabsf(t3 - r3) < thr);
     float q0 = __builtin_amdgcn_fmed3f(r0, lo_fast, hi), q1 = __builtin_amdgcn_fmed3f(r1, lo_fast, hi);
@@ -141,7 +158,7 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
   __device__ __forceinline__ uint32_t code4(const f32x4& v) const {
     bool unsure;
     const uint32_t w = code4_fast<false>(v, unsure);
-    return unsure ? exact4(v) : w;
+    return unsure ? exact4(v, w) : w;
   }
   // N independent quads: one branch for all of them
   // `u` (optional) receives the per-quad flags, for callers that have more to redo on the exact path (a NaN's ReLU)
@@ -164,7 +181,7 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
     if (any) {
 #pragma unroll
       for (int i = 0; i < N; ++i)
-        if (u[i]) w[i] = exact4(v[i]);
+        if (u[i]) w[i] = exact4(v[i], w[i]);
     }
     return any;
   }

@@ -41,7 +41,14 @@ namespace dlmcq {
 //   * everything the epilogue needs from memory (per-channel scale / code sum / bias of both pairs and, for 64-wide
 //     tiles, the fp32 shortcut tile) is requested BEFORE the first operand, so that a tile pays one memory round trip,
 //     not four in a row: at ResNet sizes most tiles have 1-8 K steps and their lifetime is latency, not work.
-template <int BN, bool DUAL, bool ADIR, bool ASYM = false, int LAB = 0>
+//   * SWAP (layers that emit only their consumer's codes - no fp32 output, no shortcut: every 3x3 and every first 1x1 of a
+//     residual block): the MFMA operands change places (weights as A, pixels as B), so a lane's 16 accumulator registers of a
+//     32-channel block are 16 CHANNELS of ONE pixel instead of 16 pixels of one channel.  The weight rows are dealt to the LDS
+//     rows in the order that makes those 16 channels consecutive (a source-side permutation of the DMA, free), so the lane
+//     quantises them and holds 16 finished bytes: no transposition of fp32 values through LDS or DPP, the ReLU folded into the
+//     quantiser's clamp, per-channel constants by broadcast ds_read_b128.  ~10 vector instructions per output element instead
+//     of ~20; the code tile (1 B per element) goes through LDS once so that the stores are whole rows.
+template <int BN, bool DUAL, bool ADIR, bool ASYM = false, int LAB = 0, bool SWAP = false>
 __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ bias,
     const int32_t* __restrict__ wsum, const float* __restrict__ s_in, const float* __restrict__ zp_in,
@@ -65,6 +72,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
   constexpr int NPAR = DUAL ? 6 : (ASYM ? 4 : 3);   // per-channel constant arrays of the epilogue: (scale, code sum, bias) per pair (+ weight offset)
   constexpr int PAR_BYTES = NPAR * BN * 4;
   static_assert(!(ASYM && DUAL), "asymmetric weights: single pair only");
+  static_assert(!(SWAP && (DUAL || ASYM)), "SWAP: plain codes-only layers");
   __shared__ __attribute__((aligned(1024))) int8_t lds[LDS_BYTES + PAR_BYTES + (ASYM ? 4 * 32 * 4 : 0)];
 
   // XCD-aware tile order: the workgroups that share an activation tile (same row block, different column blocks) are
@@ -166,7 +174,11 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
     const int64_t wrow = (int64_t)gg.R * gg.S * gg.C;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int k = n0 + (i * 4 + wave) * 16 + lrow;
+      int k = n0 + (i * 4 + wave) * 16 + lrow;
+      if constexpr (SWAP) {   // LDS row d of a 32-row block holds channel 16 ((d >> 2) & 1) + 4 (d >> 3) + (d & 3): see the epilogue
+        const int d = ((i * 4 + wave) * 16 + lrow) & 31;
+        k = (k & ~31) + 16 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3);
+      }
       f.bp[i] = k < gg.K ? ww + (int64_t)k * wrow + b_seg[i] * 16 : g_pad_table.b;
       f.b_inc[i] = k < gg.K ? BK : 0;
     }
@@ -219,6 +231,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
 
   const float zpf = zp_in ? zp_in[0] : 0.0f;
   const int zpi = (int)__builtin_rintf(zpf);
+  const float sin_early = SWAP ? s_in[0] : 0.0f;
   Feed fm;                                   // the layer's own pair
   make_feed(fm, x, w, g, zpi, shift);
   Feed fs;                                   // DUAL: the shortcut pair, reduced FIRST (its sum waits in registers)
@@ -281,6 +294,17 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
     stamp(step, 1);
     __builtin_amdgcn_s_barrier();                 // everyone's step-k bytes are in LDS; everyone left multiply(k-1)
     stamp(step, 2);
+    if constexpr (SWAP) {
+      // the per-channel constants have landed: turn (s_w, SUM qw) into the epilogue's (s_in * s_w, (shift - zp) * SUM qw) in place,
+      // once per channel instead of once per element (in the swapped layout every accumulator register is another channel)
+      if (step == 0 && tid < BN) {
+        float* pf = reinterpret_cast<float*>(lds + LDS_BYTES) + tid;
+        int* pi = reinterpret_cast<int*>(lds + LDS_BYTES) + BN + tid;
+        *pf = sin_early * *pf;
+        *pi = (shift - zpi) * *pi;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
     if constexpr (ADIR)   // the asm-loaded A fragments of this step are valid from here on (orders their uses behind the wait)
       asm volatile("" : "+v"(areg[ADIR ? U : 0][0]), "+v"(areg[ADIR ? U : 0][1]));
     // (issuing the next loads BEHIND this step's MFMAs - which execute meanwhile - was measured: the operands then arrive
@@ -325,6 +349,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
         const int brow = j * 32 + l31;
         const i32x4 bf = *reinterpret_cast<const i32x4*>(base + TILE_A + brow * BK + ((sg_ ^ ((brow >> 2) & 3)) << 4));
         if (LAB == 4) asm volatile("" ::"v"(af), "v"(bf));
+        else if constexpr (SWAP) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf, af, acc[j], 0, 0, 0);
         else acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[j], 0, 0, 0);
       }
     }
@@ -339,6 +364,47 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
     });
 
   if (STAMP && wgt) wgt[2] = __builtin_readcyclecounter();
+  if constexpr (SWAP) {
+    // lane (p = l31, h = hsel): register i of block j = channel n0 + 32 j + 16 h + i of pixel m0 + wrow0 + p
+    __builtin_amdgcn_s_barrier();                   // every wave is done with the ring (the code tile is staged there); the
+                                                    // constants' pre-pass is at least one barrier old
+    const EpiQuant eq(ep, ep.relu != 0);            // code(relu(v)) = max(code(v), code(0))
+    constexpr int SROW = BN + 16;                   // staged row: BN code bytes + 16 (conflict-free 16-byte accesses)
+    int8_t* stg = lds + wave * (32 * SROW);
+    const int8_t* par = lds + LDS_BYTES;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int cb = j * 32 + hsel * 16;
+      f32x4 y[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(par + (cb + 4 * q) * 4);
+        const i32x4 co = *reinterpret_cast<const i32x4*>(par + (BN + cb + 4 * q) * 4);
+        const f32x4 bs = bias ? *reinterpret_cast<const f32x4*>(par + (2 * BN + cb + 4 * q) * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        y[q] = f32x4{dequant1(acc[j][4 * q] + co.x, mu.x, bs.x), dequant1(acc[j][4 * q + 1] + co.y, mu.y, bs.y),
+                     dequant1(acc[j][4 * q + 2] + co.z, mu.z, bs.z), dequant1(acc[j][4 * q + 3] + co.w, mu.w, bs.w)};
+      }
+      uint32_t wq[4];
+      bool uq[4];
+      eq.code4n(y, wq, uq);
+      *reinterpret_cast<i32x4*>(stg + l31 * SROW + cb) = i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // a wave reads back only its own 32 rows
+    constexpr int LPR = BN / 16;                    // lanes per staged row
+    const int srow = lane / LPR, sseg = lane % LPR;
+#pragma unroll
+    for (int it = 0; it < 32 / (64 / LPR); ++it) {
+      const int r = it * (64 / LPR) + srow;
+      const int64_t row = m0 + wrow0 + r;
+      const i32x4 c16 = *reinterpret_cast<const i32x4*>(stg + r * SROW + sseg * 16);
+      if (row < g.M) __builtin_nontemporal_store(c16, reinterpret_cast<i32x4*>(ep.codes + row * g.K + n0 + sseg * 16));
+    }
+    if (STAMP && wgt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wgt[3] = __builtin_readcyclecounter();
+    }
+    return;
+  }
   // ---- epilogue: one rounding chain  v = (acc + (shift - zp) * SUM qw) * (s_in * s_w[k]) + b[k] ----
   const float sin = s_in[0];
   const EpiQuant eq(ep);
@@ -476,10 +542,12 @@ extern "C" int dlmcq_quantize_weight_krsc_i8(const float* w, int8_t* wq, int32_t
 struct ConvPlan {
   int bn;       // tile width: 64 or 128 channels
   bool adir;    // activations straight to registers (see the kernel)
+  bool swap;    // codes-only layers in the swapped accumulator layout (see the kernel)
 };
 
 static ConvPlan conv_plan(int64_t C, int64_t K, int64_t R, int64_t S, bool dual) {
   ConvPlan p;
+  p.swap = true;
   // 64-wide tiles: narrow outputs, widths that are no multiple of 128, and the dual kernel on short reductions (two
   // operand pairs + the shortcut sum keep 190 VGPRs at 128 columns: 655 vs 701 us on ResNet-50's first dual layer)
   const bool dual_short = dual && K <= 256 && R * S * C <= 256;
@@ -551,6 +619,14 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   } else if (ep.w_off) {     // asymmetric per-channel weights (activations direct: the row sums come from their fragments)
     if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, true, true>), DLMCQ_CONV_ARGS);
     else hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, true>), DLMCQ_CONV_ARGS);
+  } else if (plan.swap && ep.codes && !out && !ep.residual && K % plan.bn == 0 && aligned16(ep.codes)) {
+    if (plan.bn == 64) {
+      if (plan.adir) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, true, false, 0, true>), DLMCQ_CONV_ARGS);
+      else hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, false, false, 0, true>), DLMCQ_CONV_ARGS);
+    } else {
+      if (plan.adir) hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, false, 0, true>), DLMCQ_CONV_ARGS);
+      else hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, false, false, 0, true>), DLMCQ_CONV_ARGS);
+    }
   } else if (!plan.adir) {
     if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, false>), DLMCQ_CONV_ARGS);
     else hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, false>), DLMCQ_CONV_ARGS);
@@ -733,7 +809,7 @@ extern "C" int dlmcq_x_conv2d_i8_tuned(const void* x, const int8_t* w, float* ou
 #undef DLMCQ_LABK
     return launch_status();
   }
-  const ConvPlan plan{bn, adir != 0};
+  const ConvPlan plan{bn, (adir & 1) != 0, (adir & 2) == 0};     // adir bit 1: the unswapped epilogue (A/B runs)
   return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
                      x_is_unsigned, stream, ep, nullptr, &plan);
 }
