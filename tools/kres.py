@@ -22,6 +22,6 @@ for line in out.splitlines():
         k, v = t.split(":", 1)
         rows[cur][k.strip()] = v.strip()
 for name, r in rows.items():
-    dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+    dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     dem = re.sub(r"\(.*", "", dem).replace("dlmcq::", "").replace("void ", "")
     print(f"{dem:70s} vgpr {r.get('VGPRs','?'):>4} agpr {r.get('AGPRs','?'):>4} spill {r.get('VGPRs Spill','?'):>3} occ {r.get('Occupancy [waves/SIMD]','?')} lds {r.get('LDS Size [bytes/block]','?')}")
