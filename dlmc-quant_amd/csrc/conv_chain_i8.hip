@@ -103,9 +103,10 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   constexpr int WCH = (S1 + S2 + U3) * 4096;  // bytes of one chunk's weights
   constexpr int NPD = DUALH ? 2 : 1;     // constant-table DMAs per wave per chunk
   constexpr int PAR = NPD * 4 * 256;     // per-channel constants of one chunk ((scale, code sum, bias) per pair) x 64 columns
-  __shared__ __attribute__((aligned(1024))) int8_t lds[2 * WCH + 2 * PAR + 4096];
+  __shared__ __attribute__((aligned(1024))) int8_t lds[2 * WCH + 2 * PAR + 4096 + 3 * KB * 4];
   int8_t* const par0 = lds + 2 * WCH;
   int8_t* const ctile = lds + 2 * WCH + 2 * PAR;
+  int8_t* const par3 = ctile + 4096;     // GEMM 2's per-channel constants, ready-made: s_in * s_w[k] | (128 - zp) * SUM qw[k] | bias[k]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
@@ -153,8 +154,18 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
         af2[s][ks] = i32x4{(int)(t4.x ^ xw), (int)(t4.y ^ xw), (int)(t4.z ^ xw), (int)(t4.w ^ xw)};
       }
   }
+  // GEMM 2's epilogue constants, once per workgroup (its accumulator is kept with the operands swapped - weights as A, the
+  // code tile as B - so a lane owns 16 consecutive channels of one pixel and reads their constants as broadcast ds_read_b128)
+  const float sin2 = ep1.q_scale[0];                       // GEMM 2's input scale IS the quantiser the codes were made with
+  const float zpf2 = ep1.q_zp ? ep1.q_zp[0] : 0.0f;
+  const int dz2 = 128 - (int)__builtin_rintf(zpf2);
+  if (tid < KB) {
+    reinterpret_cast<float*>(par3)[tid] = sin2 * a.s_w3[tid];
+    reinterpret_cast<int*>(par3)[KB + tid] = dz2 * a.wsum3[tid];
+    reinterpret_cast<float*>(par3)[2 * KB + tid] = a.bias3 ? a.bias3[tid] : 0.0f;
+  }
   // make sure no compiler-known load is outstanding from here on (the counted waits below assume it)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   CHAIN_STAMP();   // 1: A fragments in registers
 
   // ---- addressing of the fp32 tile in the transposed (row-major) layout: group g -> row wr*32 + 8g + 4 hsel + b4 ----
@@ -175,7 +186,11 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   const int drow = wave * 16 + lrow;                       // row of a 64-row unit this lane fetches
   const int dseg = (pslot ^ ((drow >> 2) & 3)) * 16;
   const int8_t* w1p = a.w1 + (int64_t)drow * C1 + dseg;    // + chunk * 64 * C1 + s * 64
-  const int8_t* w3p = a.w3 + (int64_t)drow * a.KD + dseg;  // + unit * 64 * KD + chunk * 64
+  // W3's rows are dealt to the LDS rows so that accumulator register i of GEMM 2 (weights as the A operand) is channel
+  // 16 hsel + i of its 32-channel block: LDS row d of a block holds channel 16 ((d >> 2) & 1) + 4 (d >> 3) + (d & 3)
+  const int d3 = drow & 31;
+  const int prow3 = (drow & 32) + 16 * ((d3 >> 2) & 1) + 4 * (d3 >> 3) + (d3 & 3);
+  const int8_t* w3p = a.w3 + (int64_t)prow3 * a.KD + dseg;  // + unit * 64 * KD + chunk * 64
   const int cvo = drow < rows_here ? (int)((row0 + drow) * a.KD + dseg) : CH_BIG;   // this lane's 16 bytes of the code tile, chunk 0
   const void* const pars[4] = {a.s_w1, a.wsum1, a.bias1 ? (const void*)a.bias1 : (const void*)a.s_w1, a.s_w1};
   const int32_t* parp = static_cast<const int32_t*>(wave == 0 ? pars[0] : wave == 1 ? pars[1] : wave == 2 ? pars[2] : pars[3]) + lane;
@@ -248,9 +263,11 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     const int8_t* pp = par0 + P * PAR + (wc * 32 + l31) * 4;
     i32x16 acc;
     float extra[DUALH ? 16 : 1];
+    // (the constant (shift - zp) * SUM qw of a column is what its accumulators START from: one add per element less)
     if constexpr (DUALH) {   // the shortcut convolution first: dequantised, it waits in registers for the block's own sum
+      const int corr2 = dz1b * *reinterpret_cast<const int*>(pp + 1024 + 256);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0;
+      for (int i = 0; i < 16; ++i) acc[i] = corr2;
       const int r = wc * 32 + l31;
 #pragma unroll
       for (int s = 0; s < S2; ++s)
@@ -260,14 +277,14 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af2[s][ks], bf, acc, 0, 0, 0);
         }
       const float mult2 = sin1b * *reinterpret_cast<const float*>(pp + 1024);
-      const int corr2 = dz1b * *reinterpret_cast<const int*>(pp + 1024 + 256);
       const float bv2 = a.bias2 ? *reinterpret_cast<const float*>(pp + 1024 + 512) : 0.0f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) extra[i] = dequant1(acc[i] + corr2, mult2, bv2);
+      for (int i = 0; i < 16; ++i) extra[i] = dequant1(acc[i], mult2, bv2);
     }
     // ---- GEMM 1: rows wr*32.., columns n*64 + wc*32.. ----
+    const int corr = dz1 * *reinterpret_cast<const int*>(pp + 256);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    for (int i = 0; i < 16; ++i) acc[i] = corr;
     {
       const int r = wc * 32 + l31;
 #pragma unroll
@@ -280,12 +297,11 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     }
     // ---- epilogue 1 ----
     const float mult = sin1 * *reinterpret_cast<const float*>(pp);
-    const int corr = dz1 * *reinterpret_cast<const int*>(pp + 256);
     const float bv = a.bias1 ? *reinterpret_cast<const float*>(pp + 512) : 0.0f;
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      v[i] = dequant1(acc[i] + corr, mult, bv);
+      v[i] = dequant1(acc[i], mult, bv);
       if constexpr (DUALH) v[i] = v[i] + extra[DUALH ? i : 0];     // `out += identity`, the identity being a convolution
     }
 #pragma unroll
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
         for (int j = 0; j < U3; ++j) {
           const int kb = wc * (KB / 2) + j * 32 + l31;
           const i32x4 bf = *reinterpret_cast<const i32x4*>(wb + (S1 + S2) * 4096 + kb * 64 + (((ks * 2 + hsel) ^ ((kb >> 2) & 3)) << 4));
-          acc2[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, bf, acc2[j], 0, 0, 0);
+          acc2[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf, a2, acc2[j], 0, 0, 0);
         }
       }
     }
@@ -328,29 +344,28 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   }
 
   CHAIN_STAMP();   // chunks done
-  // ---- epilogue 2: the reduction layer's own dequantise, ReLU, its consumer's quantiser; codes only ----
-  const float sin2 = ep1.q_scale[0];                       // its input scale IS the quantiser the codes were made with
-  const float zpf2 = ep1.q_zp ? ep1.q_zp[0] : 0.0f;
-  const int dz2 = 128 - (int)__builtin_rintf(zpf2);
-  const EpiQuant eq2(ep2);
+  // ---- epilogue 2: the reduction layer's own dequantise, ReLU, its consumer's quantiser; codes only.  Lane (p = l31, hsel) holds
+  // channels wc * KB/2 + 32 j + 16 hsel + 0..15 of pixel wr * 32 + p: no transposition, the ReLU folded into the quantiser's clamp
+  // (code(relu(v)) = max(code(v), code(0))), 16 finished bytes per lane and block ----
+  const EpiQuant eq2(ep2, ep2.relu != 0);
+  const int lr2 = wr * 32 + l31;
 #pragma unroll
   for (int j = 0; j < U3; ++j) {
-    const int kb = wc * (KB / 2) + j * 32 + l31;
-    const float mult = sin2 * a.s_w3[kb];
-    const int corr = dz2 * a.wsum3[kb];
-    const float bv = a.bias3 ? a.bias3[kb] : 0.0f;
-    float v[16];
+    const int cb = wc * (KB / 2) + j * 32 + hsel * 16;
+    f32x4 y[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = dequant1(acc2[j][i] + corr, mult, bv);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
-      f32x4 y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-      if (ep2.relu) y = relu4_nan(y);
-      const int lr = wr * 32 + 8 * g + 4 * hsel + b4;
-      if (lr < rows_here)
-        *reinterpret_cast<uint32_t*>(ep2.codes + (row0 + lr) * KB + wc * (KB / 2) + j * 32 + q4 * 4) = eq2.code4(y);
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(par3 + (cb + 4 * q) * 4);
+      const i32x4 co = *reinterpret_cast<const i32x4*>(par3 + (KB + cb + 4 * q) * 4);
+      const f32x4 bs = *reinterpret_cast<const f32x4*>(par3 + (2 * KB + cb + 4 * q) * 4);
+      y[q] = f32x4{dequant1(acc2[j][4 * q] + co.x, mu.x, bs.x), dequant1(acc2[j][4 * q + 1] + co.y, mu.y, bs.y),
+                   dequant1(acc2[j][4 * q + 2] + co.z, mu.z, bs.z), dequant1(acc2[j][4 * q + 3] + co.w, mu.w, bs.w)};
     }
+    uint32_t wq[4];
+    bool uq[4];
+    eq2.code4n(y, wq, uq);
+    if (lr2 < rows_here)
+      *reinterpret_cast<i32x4*>(ep2.codes + (row0 + lr2) * KB + cb) = i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
   }
 #ifdef DLMCQ_LAB
   if (tr) {
@@ -425,7 +440,7 @@ extern "C" int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float*
   if (!x || !w || !wsum || !in_scale || !w_scale || !residual || !w2 || !wsum2 || !w_scale2 || !codes2 || !q_scale || !q2_scale)
     return DLMCQ_EINVAL;
   if (!aligned16(x) || !aligned16(w) || !aligned16(w2) || !aligned16(residual) || (out && !aligned16(out)) ||
-      (codes && !aligned16(codes)) || !aligned4(codes2))
+      (codes && !aligned16(codes)) || !aligned16(codes2))
     return DLMCQ_EALIGN;
   ChainArgs a{};
   a.x = static_cast<const int8_t*>(x); a.w1 = w; a.s_w1 = w_scale; a.wsum1 = wsum; a.bias1 = bias;
@@ -456,7 +471,7 @@ extern "C" int dlmcq_conv2d_i8_nhwc_dual_chain(const void* x, const int8_t* w, f
       !codes3 || !q_scale || !q3_scale)
     return DLMCQ_EINVAL;
   if (!aligned16(x) || !aligned16(w) || !aligned16(x2) || !aligned16(w2) || !aligned16(w3) || (out && !aligned16(out)) ||
-      (codes && !aligned16(codes)) || !aligned4(codes3))
+      (codes && !aligned16(codes)) || !aligned16(codes3))
     return DLMCQ_EALIGN;
   if (M >= (1ll << 31) || N * H2 * W2 * C2 >= (1ll << 40)) return DLMCQ_ERANGE;
   ChainArgs a{};
