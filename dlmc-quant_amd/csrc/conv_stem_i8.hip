@@ -17,7 +17,7 @@
 //
 // Max-pool commutes with the (monotone) quantiser: code(max(v)) = max(code(v)).  So the pool runs on the codes,
 // 1 byte per element instead of 4, and never sees fp32.
-#include "conv_epilogue.h"
+#include "conv_i8_common.h"
 
 namespace dlmcq {
 
@@ -296,16 +296,37 @@ __global__ __launch_bounds__(256) void conv_stem_pool_i8_kernel(const uint8_t* _
     const int pc = valid ? p : 0, qc = valid ? q : 0;            // an address that exists; the value is discarded
     return x + (((int64_t)n * g.Hp + (int64_t)pc * g.stride) * g.Wp + (int64_t)qc * g.stride) * 4 + hsel * 16;
   };
-  i32x4 af[R];
-  uint32_t n = 0, n_nx = 0;
-  int th = 0, tw = 0, th_nx = 0, tw_nx = 0;
-  bool valid = false, valid_nx = false;
-  if (blockIdx.x < g.nwork) {
-    const uint8_t* src = locate(blockIdx.x, n, th, tw, valid);
+  // Operands travel TWO items ahead (two fragment sets), by loads the compiler does not see (gload16) and one counted wait per
+  // item.  vmcnt counts loads and stores in issue order: with a distance of one, the wait for item i+1's operands at the top
+  // of the loop also waited for item i's stores, issued just before - a store round trip exposed per item (and hipcc drains the
+  // queue, vmcnt(0), whenever loads and stores are pending together).  With a distance of two the queue at the top of item k is
+  //   L(k) | stores(k-2) | L(k+1) | stores(k-1)      (7 loads per set, at most 4 stores per wave and item)
+  // and `s_waitcnt vmcnt(7)` retires L(k) while stores(k-1) and the rest of L(k+1) stay in flight.  Loads past the last item
+  // re-read the last item (the count must not depend on the item); the queue is drained before the wave ends.
+  static_assert(R <= 7, "the counted wait below assumes at most 7 loads per set (one per filter row)");
+  if (blockIdx.x >= g.nwork) return;
+  i32x4 af[2][R];
+  uint32_t n_q[2] = {0, 0};
+  int th_q[2] = {0, 0}, tw_q[2] = {0, 0};
+  bool valid_q[2] = {false, false};
+  auto fetch = [&](uint32_t w0, auto b_c) {
+    constexpr int b = decltype(b_c)::value;
+    const uint8_t* src = locate(w0 < g.nwork ? w0 : g.nwork - 1, n_q[b], th_q[b], tw_q[b], valid_q[b]);
 #pragma unroll
-    for (int r = 0; r < R; ++r) af[r] = *reinterpret_cast<const i32x4*>(src + (int64_t)r * rowbytes);
-  }
-  for (uint32_t work = blockIdx.x; work < g.nwork; work += gridDim.x) {
+    for (int r = 0; r < R; ++r) gload16<0>(af[b][r], reinterpret_cast<const int8_t*>(src + (int64_t)r * rowbytes));
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the weight fragments and constants above: nothing of the compiler's in the queue)
+  fetch(blockIdx.x, std::integral_constant<int, 0>{});
+  fetch(blockIdx.x + gridDim.x, std::integral_constant<int, 1>{});
+  auto item = [&](uint32_t work, auto b_c) {
+    constexpr int b = decltype(b_c)::value;
+    const uint32_t n = n_q[b];
+    const int th = th_q[b], tw = tw_q[b];
+    const bool valid = valid_q[b];
+    if constexpr (R == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (shorter filters: fewer loads per set - not tuned)
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("" : "+v"(af[b][r]));   // valid from here on
     i32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -313,15 +334,11 @@ __global__ __launch_bounds__(256) void conv_stem_pool_i8_kernel(const uint8_t* _
       for (int i = 0; i < 16; ++i) acc[j][i] = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const i32x4 a = i32x4{(int)(af[r].x ^ xorw), (int)(af[r].y ^ xorw), (int)(af[r].z ^ xorw), (int)(af[r].w ^ xorw)};
+      const i32x4 a = i32x4{(int)(af[b][r].x ^ xorw), (int)(af[b][r].y ^ xorw), (int)(af[b][r].z ^ xorw), (int)(af[b][r].w ^ xorw)};
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[r][j], acc[j], 0, 0, 0);
     }
-    if (work + gridDim.x < g.nwork) {                // the next item's operands travel while this one is finished
-      const uint8_t* src = locate(work + gridDim.x, n_nx, th_nx, tw_nx, valid_nx);
-#pragma unroll
-      for (int r = 0; r < R; ++r) af[r] = *reinterpret_cast<const i32x4*>(src + (int64_t)r * rowbytes);
-    }
+    fetch(work + 2 * gridDim.x, b_c);                // the operands of the item after next
     // which of this tile's pixels exist: row r of the accumulator is pixel wave*32 + r, owned by lane r of each half-wave
     // What is parked in LDS is the exact integer sum a = acc + corr, not its dequantised value: v(a) = fl(fl(float(a)*m) + b)
     // and ReLU are monotone in a for m >= 0, so max-pooling a and THEN dequantising the pooled quarter gives the same fp32
@@ -353,9 +370,9 @@ __global__ __launch_bounds__(256) void conv_stem_pool_i8_kernel(const uint8_t* _
   // ---- pool 3x3 / 2 in fp32, then the consumer's quantiser on the pooled pixels: up to 2 float4 per thread ----
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int item = threadIdx.x + u * 256;
-    if (item >= SP_TH * SP_TW * 16) continue;
-    const int pp = item >> 4, c4 = (item & 15) * 4;
+    const int pit = threadIdx.x + u * 256;
+    if (pit >= SP_TH * SP_TW * 16) continue;
+    const int pp = pit >> 4, c4 = (pit & 15) * 4;
     const int py = pp / SP_TW, px = pp - py * SP_TW;
     const int ph = th * SP_TH + py, pw = tw * SP_TW + px;
     if (ph >= g.PP || pw >= g.QP || c4 >= g.K) continue;
@@ -382,8 +399,16 @@ __global__ __launch_bounds__(256) void conv_stem_pool_i8_kernel(const uint8_t* _
     if (ep.codes) __builtin_nontemporal_store(eq.code4(m), reinterpret_cast<uint32_t*>(ep.codes + at));
   }
   __syncthreads();     // the region is rewritten by the next item
-  n = n_nx; th = th_nx; tw = tw_nx; valid = valid_nx;
+  };
+  for (uint32_t work = blockIdx.x;;) {
+    item(work, std::integral_constant<int, 0>{});
+    work += gridDim.x;
+    if (work >= g.nwork) break;
+    item(work, std::integral_constant<int, 1>{});
+    work += gridDim.x;
+    if (work >= g.nwork) break;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the loads issued past the last item
 }
 
 // ------------------------------------------------------------------------- max-pool on codes
