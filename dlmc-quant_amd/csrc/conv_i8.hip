@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
   constexpr int NPAR = DUAL ? 6 : (ASYM ? 4 : 3);   // per-channel constant arrays of the epilogue: (scale, code sum, bias) per pair (+ weight offset)
   constexpr int PAR_BYTES = NPAR * BN * 4;
   static_assert(!(ASYM && DUAL), "asymmetric weights: single pair only");
-  static_assert(!(SWAP && (DUAL || ASYM)), "SWAP: plain codes-only layers");
+  static_assert(!(SWAP && DUAL), "SWAP: codes-only layers with one operand pair");
   __shared__ __attribute__((aligned(1024))) int8_t lds[LDS_BYTES + PAR_BYTES + (ASYM ? 4 * 32 * 4 : 0)];
 
   // XCD-aware tile order: the workgroups that share an activation tile (same row block, different column blocks) are
@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
         int* pi = reinterpret_cast<int*>(lds + LDS_BYTES) + BN + tid;
         *pf = sin_early * *pf;
         *pi = (shift - zpi) * *pi;
+        if constexpr (ASYM) pf[3 * BN] = sin_early * pf[3 * BN];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
@@ -372,6 +373,12 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
     constexpr int SROW = BN + 16;                   // staged row: BN code bytes + 16 (conflict-free 16-byte accesses)
     int8_t* stg = lds + wave * (32 * SROW);
     const int8_t* par = lds + LDS_BYTES;
+    float s0f = 0.0f;     // ASYM: SUM x' / s_in of this lane's pixel (lanes p and p + 32 hold the two halves of pixel p's operand bytes)
+    if constexpr (ASYM) {
+      s0 += __shfl_xor(s0, 32, 64);
+      s0 += (shift - zpi) * (g.R * g.S * g.C);
+      s0f = (float)s0;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int cb = j * 32 + hsel * 16;
@@ -383,6 +390,10 @@ __global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 6
         const f32x4 bs = bias ? *reinterpret_cast<const f32x4*>(par + (2 * BN + cb + 4 * q) * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         y[q] = f32x4{dequant1(acc[j][4 * q] + co.x, mu.x, bs.x), dequant1(acc[j][4 * q + 1] + co.y, mu.y, bs.y),
                      dequant1(acc[j][4 * q + 2] + co.z, mu.z, bs.z), dequant1(acc[j][4 * q + 3] + co.w, mu.w, bs.w)};
+        if constexpr (ASYM) {
+          const f32x4 wo = *reinterpret_cast<const f32x4*>(par + (3 * BN + cb + 4 * q) * 4);
+          y[q] = f32x4{y[q].x + s0f * wo.x, y[q].y + s0f * wo.y, y[q].z + s0f * wo.z, y[q].w + s0f * wo.w};
+        }
       }
       uint32_t wq[4];
       bool uq[4];
@@ -616,6 +627,9 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   if (seg2) {
     if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, true, true>), DLMCQ_CONV_ARGS);
     else hipLaunchKernelGGL((conv_i8_mfma_kernel<128, true, true>), DLMCQ_CONV_ARGS);
+  } else if (ep.w_off && plan.swap && ep.codes && !out && !ep.residual && K % plan.bn == 0 && aligned16(ep.codes)) {
+    if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, true, true, 0, true>), DLMCQ_CONV_ARGS);
+    else hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, true, 0, true>), DLMCQ_CONV_ARGS);
   } else if (ep.w_off) {     // asymmetric per-channel weights (activations direct: the row sums come from their fragments)
     if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, true, true>), DLMCQ_CONV_ARGS);
     else hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, true>), DLMCQ_CONV_ARGS);

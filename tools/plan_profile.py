@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-layer timing of the fused plan (HIP events around every plan node).  python tools/plan_profile.py [model] [batch]"""
+"""Per-layer timing of the fused plan (HIP events around every plan node).  python tools/plan_profile.py [model] [batch]
+(model mobileone_s1 is profiled as BASELINE config 5: QBase W4A8, asymmetric per-channel weights)"""
 import json
 import os
 import sys
@@ -18,9 +19,16 @@ name = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 dev = "cuda:0"
 torch.manual_seed(2333)
-model = merge_bn(W.MODELS[name]().to(dev).eval(), inplace=True, allow_missing=True)
-quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=True)
-x = torch.relu(torch.randn(batch, 3, 224, 224, device=dev)).contiguous(memory_format=torch.channels_last)
+if name == "mobileone_s1":
+    model = W.MODELS[name]().to(dev).eval()
+    quantize_model(model, {"weight": {"enable": True, "type": "minmax_channel", "args": {"n_bits": 4, "signed": False}},
+                           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+                           "exclude_layers": [], "override_options": []}, None)
+    x = torch.relu(torch.randn(batch, 3, 224, 224, device=dev))
+else:
+    model = merge_bn(W.MODELS[name]().to(dev).eval(), inplace=True, allow_missing=True)
+    quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=True)
+    x = torch.relu(torch.randn(batch, 3, 224, 224, device=dev)).contiguous(memory_format=torch.channels_last)
 recs = []
 with torch.no_grad():
     model(x)
