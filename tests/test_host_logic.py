@@ -215,3 +215,16 @@ def test_chain_kernel_listing_has_no_spill_in_its_loop_and_keeps_its_store_wait_
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "lint_chain.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_first_layer_kernel_listing_leaves_in_flight_fragments_alone():
+    """tools/lint_stem.py on the cross-compiled listing: conv_stem_pool_i8_kernel<7> loads its operand fragments by inline asm two
+    items ahead; nothing may read, copy or spill them between issue and the counted wait."""
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "lint_stem.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
