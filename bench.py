@@ -25,6 +25,9 @@ One JSON line on rank 0.  Besides the contract fields:
   first_batch          one more calibrating forward (every observer re-armed): SURVEY 8(d)'s "first batch, observer on" (module
                        path; includes one device-to-host read per layer - is the zero point an integer? - that serialises launches)
   roofline_fake_quant  the stand-alone fake-quant kernel, measured live on BASELINE configs[1]'s tensor
+  quant_work_8d        SURVEY.md 8(d)'s own accounting of the step: the bytes the reference's fake-quant passes move for this
+                       batch (8 B per fake-quantised activation / weight element) over the WHOLE step's time, against 8 TB/s.
+                       An equivalent rate, not HBM traffic: the fused plan never moves most of those bytes.
   cpu_baseline         the CPU port of the same layer stack (oracle/), timed on this box's host cores on a bounded sample
                        (N = 1 only): all granted cores and one thread, median and min
 """
@@ -377,6 +380,17 @@ def main():
                        "families": {k: {"launches": f["launches"], "GBps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)}
                                     for k, f in fam.items() if f["ms"] > 0}},
     }
+    if args.model == "resnet50":
+        # 85 315 584 B per image of activations + 204 023 296 B of weights per forward at 8 B per
+        # fake-quantised element; "5.49 ms at roofline" for batch 512.  The whole step (convolutions included) against that.
+        qb = 85315584 * args.batch + 204023296
+        step_s = elapsed / args.steps
+        out["quant_work_8d"] = {"algorithmic_bytes_per_step_per_gpu": qb, "equivalent_GBps": round(qb / step_s / 1e9, 1),
+                                "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": round(qb / step_s / 1e9 / HBM_PEAK_GBPS, 4),
+                                "note": "SURVEY.md 8(d) accounting: bytes the reference's stand-alone fake-quant passes move per step "
+                                        "/ the whole step's time (convolutions included); an equivalent rate - in the fused plan "
+                                        "the quantisers run in the conv epilogues and most of these bytes never exist"}
     if conv["ms"] + chain["ms"] > 0:     # both int8 matrix-core kernels together
         out["conv_i8"] = {"launches": conv["launches"] + chain["launches"], "ms_per_step": round((conv["ms"] + chain["ms"]) / psteps, 3),
                           "GBps": round((conv["bytes"] + chain["bytes"]) / ((conv["ms"] + chain["ms"]) * 1e-3) / 1e9, 1),

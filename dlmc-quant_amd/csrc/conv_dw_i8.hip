@@ -71,7 +71,9 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
   const int64_t total = (int64_t)g.N * g.P * g.Q * C16;
   const uint32_t zpw = (uint32_t)(zpi & 0xff) * 0x01010101u;
   const uint32_t xw = x_signed ? 0u : 0x80808080u;
-  const EpiQuant eq(ep);
+  // codes-only layers: the ReLU is folded into the quantiser's clamp (code(relu(v)) = max(code(v), code(0)): conv_epilogue.h)
+  const bool fold = ep.relu && !out && ep.codes;
+  const EpiQuant eq(ep, fold);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t pix = fdiv((uint32_t)i, g.cdiv);                 // (cdiv divides by C / 16 here)
     const int c16 = (int)((uint32_t)i - pix * (uint32_t)C16);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
         if (bias) r = r + tp.z;
         v[j] = r;
       }
-      if (ep.relu) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
+      if (ep.relu && !fold) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
       const int64_t at = (int64_t)pix * g.C4 * 4 + c + d * 4;
       if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
       if (ep.codes) codes[d] = eq.code4(v);

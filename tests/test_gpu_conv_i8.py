@@ -224,3 +224,61 @@ def test_conv_i8_random_shapes_against_float64():
         _, wc = K.fake_quant(want, q_s, emit.zero_point, 0, 255, N.FORM_ZEROPOINT, codes="i8", want_y=False)
         out, cds = K.conv2d_i8(*args, residual=res, relu=True, emit=emit, **kw)
         assert torch.equal(out, want) and torch.equal(cds, wc), tag + " fused epilogue"
+
+
+def test_codes_only_epilogue_random_shapes_match_the_two_pass_path():
+    """Layers that emit only their consumer's codes run in the swapped accumulator layout (conv_i8_mfma_kernel<..., SWAP>: a lane
+    owns 16 channels of one pixel, the ReLU is folded into the quantiser's clamp).  80 random geometries - widths that do and do
+    not qualify (K % tile width), ragged row tiles, all four quantiser forms incl. signed ranges and non-zero offsets, ReLU on and
+    off, bias on and off, symmetric and asymmetric weights - against the same convolution's fp32 output put through ReLU and the
+    stand-alone fake-quant kernel: the codes must be the same bytes."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = gen(1234)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+    forms = [N.FORM_ZEROPOINT, N.FORM_SYMMETRIC, N.FORM_EMULATE, N.FORM_QBASE]
+    done = 0
+    while done < 80:
+        n, c, k = ri(1, 3), 64 * ri(1, 3), [64, 128, 192, 256, 72, 32][ri(0, 5)]
+        r = [1, 3][ri(0, 1)]
+        stride, pad = ri(1, 2), ri(0, 1)
+        h, w = ri(2, 13), ri(2, 13)
+        p, q = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - r) // stride + 1
+        if p < 1 or q < 1:
+            continue
+        done += 1
+        unsigned = done % 2 == 0
+        lo, hi = (0, 255) if unsigned else (-127, 127)
+        codes = torch.randint(lo, hi + 1, (n, c, h, w), generator=g).to(torch.uint8 if unsigned else torch.int8)
+        zp = float(ri(0, 9)) if unsigned else 0.0
+        wt = torch.randn(k, c, r, r, generator=g) * 0.05
+        s_w = wt.abs().amax(dim=(1, 2, 3)) / 127 + 1e-6
+        bias = torch.randn(k, generator=g).to(DEV) if done % 3 else None
+        w_off = (torch.randn(k, generator=g) * 0.01).to(DEV) if done % 4 == 1 else None
+        wq, wsum = K.quantize_weight_krsc(wt.to(DEV), s_w.to(DEV), -127, 127)
+        cd = codes.to(DEV).contiguous(memory_format=torch.channels_last)
+        args = (cd, wq, wsum, bias, torch.tensor([0.0173], device=DEV), torch.tensor([zp], device=DEV), s_w.to(DEV))
+        kw = dict(stride=stride, padding=pad, w_offset=w_off)
+        relu = done % 5 != 0
+        form = forms[done % 4]
+        ref = K.conv2d_i8(*args, **kw)
+        want = torch.relu(ref) if relu else ref
+        spread = float(want.abs().max()) + 1e-3
+        if form == N.FORM_ZEROPOINT:
+            qlo, qhi, q_s, q_z = 0, 255, spread / 200, float(ri(0, 40))
+        elif form == N.FORM_SYMMETRIC:
+            qlo, qhi, q_s, q_z = -127, 127, spread / 100, 0.0
+        elif form == N.FORM_EMULATE:
+            qlo, qhi, q_s, q_z = (0, 255, spread / 300, -0.37 * spread) if done % 8 < 4 else (-128, 127, spread / 90, 0.11 * spread)
+        else:
+            qlo, qhi, q_s, q_z = -127, 127, spread / 110, 0.05 * spread
+        gq = 1.0 / (want.numel() * 127) ** 0.5 if form == N.FORM_QBASE else 0.0
+        q_st, q_zt = torch.tensor([q_s], device=DEV), torch.tensor([q_z], device=DEV)
+        emit = K.EmitCodes(q_st, q_zt, qlo, qhi, form, gq)
+        _, wc = K.fake_quant(want, q_st, q_zt, qlo, qhi, form, g=gq, codes="i8", want_y=False)
+        tag = f"case {done}: n{n} c{c} {h}x{w} k{k} r{r} s{stride} p{pad} form {form} relu {relu} asym {w_off is not None}"
+        none, cds = K.conv2d_i8(*args, relu=relu, emit=emit, want_out=False, **kw)
+        assert none is None
+        assert torch.equal(cds.view(torch.uint8), wc.view(torch.uint8)), tag
