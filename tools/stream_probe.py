@@ -53,3 +53,27 @@ with torch.no_grad():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 10 * 1e3
         print(f"{S} stream(s) skew {skew_us} us: {ms:.3f} ms  {batch / ms * 1e3:.0f} images/s  identical={torch.equal(out, ref)}", flush=True)
+    # free-running shares: no join between steps (each stream runs its share of every step back to back; one join at the end)
+    for S in (2, 3):
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        parts = list(x.chunk(S, dim=0))
+
+        def run_free(steps):
+            cur = torch.cuda.current_stream()
+            for s in streams:
+                s.wait_stream(cur)
+            outs = [None] * S
+            for _ in range(steps):
+                for i, s in enumerate(streams):
+                    with torch.cuda.stream(s):
+                        outs[i] = plan(parts[i])
+            for s in streams:
+                cur.wait_stream(s)
+            return torch.cat(outs)
+        run_free(3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run_free(10)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        print(f"{S} free-running stream(s), no join between steps: {ms:.3f} ms  {batch / ms * 1e3:.0f} images/s  identical={torch.equal(out, ref)}", flush=True)
