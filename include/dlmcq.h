@@ -390,7 +390,8 @@ int dlmcq_conv2d_i8_nhwc_dual(const void* x, const int8_t* w, float* out, const 
  * Q must be an unsigned 8-bit quantiser (q_lo = 0, q_hi = 255: the second reduction reads uint8 codes).
  * Supported: (C, K2) in {(64,64), (64,128), (128,128), (128,256), (256,256)}, K % 64 == 0, M*K*4 < 2^31 - 64 Ki
  * (anything else: DLMCQ_EINVAL / DLMCQ_ERANGE; callers fall back to the two separate calls).
- * rows_per_tile: pixels per workgroup, 1..64; <= 0: 64.
+ * rows_per_tile: pixels per workgroup, 1..64; <= 0: 64.  x, w, w2, residual, out, codes and codes2 must be 16-byte aligned
+ * (DLMCQ_EALIGN otherwise).
  */
 int dlmcq_conv2d_i8_nhwc_chain(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
                                const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t M,
