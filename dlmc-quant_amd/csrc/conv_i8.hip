@@ -49,7 +49,7 @@ namespace dlmcq {
 //     quantiser's clamp, per-channel constants by broadcast ds_read_b128.  ~10 vector instructions per output element instead
 //     of ~20; the code tile (1 B per element) goes through LDS once so that the stores are whole rows.
 template <int BN, bool DUAL, bool ADIR, bool ASYM = false, int LAB = 0, bool SWAP = false>
-__global__ __launch_bounds__(256, (DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
+__global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ bias,
     const int32_t* __restrict__ wsum, const float* __restrict__ s_in, const float* __restrict__ zp_in,
     const float* __restrict__ s_w, ConvGeom g, int shift, ConvEpi ep, ConvSeg2 sg) {
@@ -571,6 +571,7 @@ static ConvPlan conv_plan(int64_t C, int64_t K, int64_t R, int64_t S, bool dual)
     // (with the swapped epilogue the 1024 / 2048-deep reductions are 2-5 % faster on 128-wide tiles: 59.2 vs 62.4, 60.5 vs 61.9 us)
     p.bn = (C >= 1024 && K % 128 == 0) ? 128 : 64;
     p.adir = false;
+    if (C >= 2048 && K % 256 == 0) p.bn = 256;      // (7x7 stage: 54.4 vs 61.2 us; conv_launch falls back to 128 when the layer is not codes-only)
   } else if (R * S == 1 && !dual && K % 64 == 0 && K >= 4 * C && C <= 256) {
     // 1x1 expansions (the block-end layers: HBM streams with a short reduction): 64-wide tiles, 3-6 % faster at every stage
     // (tools/conv_lab.py); activations through the ring once a row is >= 128 bytes
@@ -578,6 +579,10 @@ static ConvPlan conv_plan(int64_t C, int64_t K, int64_t R, int64_t S, bool dual)
     p.adir = C < 128;
   } else {
     p.adir = true;
+    // K-loop-bound 3x3 layers with 72 K steps per tile (512 channels): 256-wide tiles - a third fewer operand bytes per MAC through
+    // the CU's vector-memory path, at two workgroups per CU - pay once the epilogue is the swapped one: 512->512 at 7^2 111.7 -> 91.5 us
+    // on cold buffers (tools/conv_lab.py), 95 -> 81 us in the plan; 256->256 at 14^2 gains 6 % cold and nothing in the plan (128 kept)
+    if (R * S > 1 && !dual && C >= 512 && K % 256 == 0) p.bn = 256;
   }
   return p;
 }
@@ -612,7 +617,16 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int8_t* xs = reinterpret_cast<const int8_t*>(x);
   const ConvPlan plan = forced ? *forced : conv_plan(C, K, R, S, seg2 != nullptr);
-  if (plan.bn != 64 && plan.bn != 128) return DLMCQ_EINVAL;
+  if (plan.bn != 64 && plan.bn != 128 && plan.bn != 256) return DLMCQ_EINVAL;
+  // 256-wide tiles exist for the swapped codes-only layers only (one third fewer operand bytes per MAC, two workgroups per CU)
+  const bool swap_ok = plan.swap && ep.codes && !out && !ep.residual && K % plan.bn == 0 && aligned16(ep.codes);
+  if (plan.bn == 256 && (seg2 || ep.w_off || !swap_ok)) {
+    if (forced) return DLMCQ_EINVAL;
+    ConvPlan p2 = plan;                  // (fp32 outputs, shortcuts, asymmetric weights: the 128-wide kernels)
+    p2.bn = 128;
+    return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
+                       x_is_unsigned, stream, ep, seg2, &p2);
+  }
   g.nblk_m = (int)((M + CV_BM - 1) / CV_BM);
   g.nblk_n = (int)((K + plan.bn - 1) / plan.bn);
   const int64_t nwg = (int64_t)g.nblk_m * g.nblk_n;
@@ -634,7 +648,10 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   } else if (ep.w_off) {     // asymmetric per-channel weights (activations direct: the row sums come from their fragments)
     if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, true, true>), DLMCQ_CONV_ARGS);
     else hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, true>), DLMCQ_CONV_ARGS);
-  } else if (plan.swap && ep.codes && !out && !ep.residual && K % plan.bn == 0 && aligned16(ep.codes)) {
+  } else if (swap_ok && plan.bn == 256) {
+    if (plan.adir) hipLaunchKernelGGL((conv_i8_mfma_kernel<256, false, true, false, 0, true>), DLMCQ_CONV_ARGS);
+    else hipLaunchKernelGGL((conv_i8_mfma_kernel<256, false, false, false, 0, true>), DLMCQ_CONV_ARGS);
+  } else if (swap_ok) {
     if (plan.bn == 64) {
       if (plan.adir) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, true, false, 0, true>), DLMCQ_CONV_ARGS);
       else hipLaunchKernelGGL((conv_i8_mfma_kernel<64, false, false, false, 0, true>), DLMCQ_CONV_ARGS);

@@ -33,6 +33,8 @@ CASES = {
     "c3": (256, 14, 256, 3, 1, False, False, True),
     "d3": (256, 14, 1024, 1, 1, True, True, True),
     "b3": (1024, 14, 256, 1, 1, False, False, True),
+    "b3w": (1024, 14, 512, 1, 1, False, False, True),
+    "c3s": (256, 28, 256, 3, 2, False, False, True),
     "c4": (512, 7, 512, 3, 1, False, False, True),
     "d4": (512, 7, 2048, 1, 1, True, True, True),
     "b4": (2048, 7, 512, 1, 1, False, False, True),
