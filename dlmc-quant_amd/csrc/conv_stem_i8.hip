@@ -103,7 +103,11 @@ constexpr int ST_EP_LD = 68;   // floats per staged row (64 + 4 pad)
 // ASYM: asymmetric per-channel weights w' = qw * s_w[k] + o_w[k] (ops.py:129-136; ep.w_off): the extra term o_w[k] * SUM x' of the
 // receptive field, SUM x' = s_in * (SUM q' + (shift - zp) * R * S * C), the code sum taken from the operand fragments with
 // v_dot4_i32_i8 against a 0/1 mask of the bytes that are real taps and real channels (as in conv_i8.hip's ASYM instantiation).
-template <int R, bool ASYM = false>
+// SWAP (codes-only output, K a multiple of 64): operands exchanged as in conv_i8.hip's SWAP kernels - a lane's accumulators are 16
+// consecutive channels of ONE pixel (the weight fragments are loaded in the matching row order), so the epilogue needs no
+// transposition through LDS, folds the ReLU into the quantiser's clamp and reads its per-channel constants, pre-multiplied once
+// per workgroup, as broadcast ds_read_b128; the per-pixel code sum of ASYM is a per-lane scalar.
+template <int R, bool ASYM = false, bool SWAP = false>
 __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                            float* __restrict__ out, const float* __restrict__ bias,
                                                            const int32_t* __restrict__ wsum, const float* __restrict__ s_in,
@@ -117,13 +121,15 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
   const float zpf = zp_in ? zp_in[0] : 0.0f;
   const int zpi = (int)__builtin_rintf(zpf);
   const float sin = s_in[0];
-  const EpiQuant eq(ep);
+  const EpiQuant eq(ep, SWAP && ep.relu);
 
   // weights of this slab: fragment (r, j) = 16 bytes of channel n0 + j*32 + (lane & 31), taps hsel*4 .. +3
+  // (SWAP: row d of a block is channel 16 ((d >> 2) & 1) + 4 (d >> 3) + (d & 3): accumulator register i = channel 16 hsel + i)
   i32x4 bf[R][2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int k = n0 + j * 32 + (lane & 31);
+    const int d31 = lane & 31;
+    const int k = n0 + j * 32 + (SWAP ? 16 * ((d31 >> 2) & 1) + 4 * (d31 >> 3) + (d31 & 3) : d31);
 #pragma unroll
     for (int r = 0; r < R; ++r)
       bf[r][j] = k < g.K ? *reinterpret_cast<const i32x4*>(w + ((int64_t)k * R + r) * 32 + hsel * 16) : i32x4{0, 0, 0, 0};
@@ -155,6 +161,20 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
     }
   }
 
+  // SWAP: the epilogue's constants by channel of this slab, ready-made: s_in * s_w | (shift - zp) * SUM qw | bias | s_in * o_w
+  __shared__ __attribute__((aligned(16))) float ctab[SWAP ? 4 * 64 : 4];
+  if constexpr (SWAP) {
+    if (threadIdx.x < 64) {
+      const int k = n0 + threadIdx.x;
+      const bool ok = k < g.K;
+      ctab[threadIdx.x] = ok ? sin * s_w[k] : 0.0f;
+      reinterpret_cast<int*>(ctab)[64 + threadIdx.x] = ok ? (shift - zpi) * wsum[k] : 0;
+      ctab[128 + threadIdx.x] = (ok && bias) ? bias[k] : 0.0f;
+      ctab[192 + threadIdx.x] = (ASYM && ok) ? sin * ep.w_off[k] : 0.0f;
+    }
+    __syncthreads();
+  }
+
   for (int tile = blockIdx.x * 4 + wave; tile < g.ntiles; tile += gridDim.x * 4) {
     const int64_t m0 = (int64_t)tile * 32;
     int64_t m = m0 + (lane & 31);
@@ -183,7 +203,50 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
         s0 = __builtin_amdgcn_sdot4(a.w, maskw[3], s0, false);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[r][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j)
+        acc[j] = SWAP ? __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[r][j], a, acc[j], 0, 0, 0)
+                      : __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[r][j], acc[j], 0, 0, 0);
+    }
+    if constexpr (SWAP) {
+      // lane (p = lane & 31, hsel): channels n0 + 32 j + 16 hsel + 0..15 of pixel m0 + p
+      float s0f = 0.0f;
+      if (ASYM) {
+        s0 += __shfl_xor(s0, 32, 64);
+        s0 += (shift - zpi) * (R * g.S * g.C);
+        s0f = (float)s0;
+      }
+      uint8_t* cst = reinterpret_cast<uint8_t*>(stg);       // this wave's stage: 32 rows x 80 bytes of codes
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cb = j * 32 + hsel * 16;
+        f32x4 y[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 mu = *reinterpret_cast<const f32x4*>(ctab + cb + 4 * q4);
+          const i32x4 co = *reinterpret_cast<const i32x4*>(ctab + 64 + cb + 4 * q4);
+          const f32x4 bs = *reinterpret_cast<const f32x4*>(ctab + 128 + cb + 4 * q4);
+          y[q4] = f32x4{(float)(acc[j][4 * q4] + co.x) * mu.x + bs.x, (float)(acc[j][4 * q4 + 1] + co.y) * mu.y + bs.y,
+                        (float)(acc[j][4 * q4 + 2] + co.z) * mu.z + bs.z, (float)(acc[j][4 * q4 + 3] + co.w) * mu.w + bs.w};
+          if (ASYM) {
+            const f32x4 wo = *reinterpret_cast<const f32x4*>(ctab + 192 + cb + 4 * q4);
+            y[q4] = f32x4{y[q4].x + s0f * wo.x, y[q4].y + s0f * wo.y, y[q4].z + s0f * wo.z, y[q4].w + s0f * wo.w};
+          }
+        }
+        uint32_t wq[4];
+        bool uq[4];
+        eq.code4n(y, wq, uq);
+        *reinterpret_cast<i32x4*>(cst + (lane & 31) * 80 + cb) = i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave reads back only what it wrote itself
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {                     // 16 rows x 64 bytes per pass: whole rows
+        const int r = it * 16 + (lane >> 2);
+        const int64_t row = m0 + r;
+        const i32x4 c16 = *reinterpret_cast<const i32x4*>(cst + r * 80 + (lane & 3) * 16);
+        if (row < g.M) __builtin_nontemporal_store(c16, reinterpret_cast<i32x4*>(ep.codes + row * g.K + n0 + (lane & 3) * 16));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next tile overwrites the stage
+      continue;
     }
     float s0r[ASYM ? 16 : 1];
     if (ASYM) {      // lanes p and p + 32 hold the two tap halves of pixel p; the sums go through LDS into the accumulator layout
@@ -564,6 +627,12 @@ static int stem_launch(const void* xpad, const int8_t* w, float* out, const floa
     if (w_offset) hipLaunchKernelGGL((conv_stem_i8_kernel<RR, true>), DLMCQ_STEM_ARGS); \
     else hipLaunchKernelGGL((conv_stem_i8_kernel<RR, false>), DLMCQ_STEM_ARGS);         \
     break;
+  // 3 x 3 first layers that emit only codes (RepVGG, MobileOne): the swapped epilogue
+  if (R == 3 && !out && codes && K % 64 == 0 && aligned16(codes)) {
+    if (w_offset) hipLaunchKernelGGL((conv_stem_i8_kernel<3, true, true>), DLMCQ_STEM_ARGS);
+    else hipLaunchKernelGGL((conv_stem_i8_kernel<3, false, true>), DLMCQ_STEM_ARGS);
+    return launch_status();
+  }
   switch ((int)R) {
     DLMCQ_STEM_CASE(1) DLMCQ_STEM_CASE(2) DLMCQ_STEM_CASE(3) DLMCQ_STEM_CASE(4) DLMCQ_STEM_CASE(5) DLMCQ_STEM_CASE(6)
     default:
