@@ -83,9 +83,14 @@ def main():
             rc = fn(N.ptr(xs[i]), N.ptr(wq), N.ptr(outs[i]) if want_out else None, N.ptr(bias), N.ptr(wsum), N.ptr(s_in), N.ptr(zp),
                     N.ptr(s_w), n, h, h, c, k, r, r, stride, r // 2, 1, 1, N.ptr(ress[i]) if res else None, 1, N.ptr(cods[i]),
                     N.ptr(q_s), N.ptr(q_z), 0, 255, N.FORM_ZEROPOINT, 0.0, N.stream_ptr(), kn[0], kn[1], kn[2], kn[3])
+            if rc == -1:
+                return False                      # this knob set does not exist for this layer (DLMCQ_EINVAL): skipped
             if rc:
                 raise RuntimeError(f"{name} {kn}: rc {rc}")
+            return True
         ref = None
+        all_knobs = knobs
+        knobs = [kn for kn in all_knobs if run(kn, 0)]
         times = {kn: [] for kn in knobs}
         for kn in knobs:
             run(kn, 0)
@@ -114,6 +119,7 @@ def main():
         print(line, flush=True)
         del xs, ress, outs, cods
         torch.cuda.empty_cache()
+        knobs = all_knobs
 
 
 if __name__ == "__main__":
