@@ -119,8 +119,10 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + 64 * (size_t)blockIdx.x : nullptr;
   int trn = 0;
 #define CHAIN_STAMP() do { if (tr && trn < 56) tr[trn++] = __builtin_readcyclecounter(); } while (0)
+#define CHAIN_FINE(k) do { if (tr && n == 1) tr[56 + (k)] = __builtin_readcyclecounter(); } while (0)   // chunk 1 in detail (tools/chain_trace.py)
 #else
 #define CHAIN_STAMP() do { } while (0)
+#define CHAIN_FINE(k) do { } while (0)
 #endif
   CHAIN_STAMP();   // 0: start
 
@@ -295,6 +297,10 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s][ks], bf, acc, 0, 0, 0);
         }
     }
+#ifdef DLMCQ_LAB
+    if (tr && n == 1) asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[15]));   // (GEMM 1 retired)
+#endif
+    CHAIN_FINE(0);
     // ---- epilogue 1 ----
     const float mult = sin1 * *reinterpret_cast<const float*>(pp);
     const float bv = a.bias1 ? *reinterpret_cast<const float*>(pp + 512) : 0.0f;
@@ -315,6 +321,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
       const uint32_t c = eq1.code4(y);
       const int R = wr * 32 + 8 * g + 4 * hsel + b4;
       *reinterpret_cast<uint32_t*>(ctile + R * 64 + (((wc * 2 + (q4 >> 2)) ^ ((R >> 2) & 3)) << 4) + (q4 & 3) * 4) = c;
+      CHAIN_FINE(1 + g);
     }
     CHAIN_STAMP();   // 3 + 3n: GEMM 1 + epilogue 1 issued
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
