@@ -155,6 +155,148 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
   }
 }
 
+// 3 x 3, stride 1, padding 1 (every depthwise layer of a MobileOne stage but its first): TWO horizontally adjacent output pixels
+// per thread.  The pair shares 6 of its 9 + 9 taps (12 loads instead of 18), and the byte transposition is done per FILTER ROW -
+// a dword holds columns q-1 .. q+2 of one channel - so one transposition serves both pixels: pixel A multiplies it with
+// [w0 w1 w2 0], pixel B with [0 w0 w1 w2] (both packed once per workgroup).  Per output element: 3 instead of 5 byte permutes, the
+// channel's LDS records read once per pair.  Same integer sums, same fp32 chain: bit-identical to conv_dw3_i8_kernel.
+__global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4* __restrict__ x, const int8_t* __restrict__ w,
+                                                                   float* __restrict__ out, const float* __restrict__ bias,
+                                                                   const float* __restrict__ s_in, const float* __restrict__ zp_in,
+                                                                   const float* __restrict__ s_w, const float* __restrict__ o_w,
+                                                                   DwGeom g, int x_signed, ConvEpi ep) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dw_lds[];
+  const int C = g.C4 * 4, C16 = g.C4 >> 2;
+  u32x4* tabA = reinterpret_cast<u32x4*>(dw_lds);            // [16][C16]: {row 0, row 1, row 2 of pixel A's weights, dzw}
+  u32x4* tabB = tabA + C;                                    // [16][C16]: {rows of pixel B's weights (one byte up), -}
+  f32x4* tabp = reinterpret_cast<f32x4*>(tabB + C);          // [16][C16]: {m, mo, b, -}
+  const float sin = s_in[0], zp = zp_in ? zp_in[0] : 0.0f;
+  const int zpi = (int)zp;
+  const int dz = (x_signed ? 0 : 128) - zpi;
+  const bool asym = o_w != nullptr;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    uint32_t ra[3];
+    int sum = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      ra[r] = 0u;
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const int wv = w[(r * 3 + s_) * C + c];
+        sum += wv;
+        ra[r] |= (uint32_t)(wv & 0xff) << (8 * s_);
+      }
+    }
+    const int slot = (c & 15) * C16 + (c >> 4);
+    tabA[slot] = u32x4{ra[0], ra[1], ra[2], (uint32_t)(dz * sum)};
+    tabB[slot] = u32x4{ra[0] << 8, ra[1] << 8, ra[2] << 8, 0u};
+    tabp[slot] = f32x4{sin * s_w[c], asym ? sin * o_w[c] : 0.0f, bias ? bias[c] : 0.0f, 0.0f};
+  }
+  __syncthreads();
+  const int QP = (g.Q + 1) >> 1;                             // pixel pairs per output row
+  const int64_t total = (int64_t)g.N * g.P * QP * C16;
+  const uint32_t zpw = (uint32_t)(zpi & 0xff) * 0x01010101u;
+  const uint32_t xw = x_signed ? 0u : 0x80808080u;
+  const bool fold = ep.relu && !out && ep.codes;
+  const EpiQuant eq(ep, fold);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t pr = fdiv((uint32_t)i, g.cdiv);                  // (cdiv divides by C / 16)
+    const int c16 = (int)((uint32_t)i - pr * (uint32_t)C16);
+    const uint32_t t = fdiv(pr, g.qdiv);                            // (qdiv divides by QP here)
+    const int qp = (int)(pr - t * (uint32_t)QP);
+    const uint32_t n = fdiv(t, g.pdiv);
+    const int p = (int)(t - n * (uint32_t)g.P);
+    const int q = 2 * qp;
+    const int h0 = p - 1, w0 = q - 1;                               // rows h0 .. h0+2, columns w0 .. w0+3
+    const bool hasB = q + 1 < g.Q;
+    u32x4 a[3][4];
+    const u32x4* img = x + (int64_t)n * g.H * g.W * C16 + c16;
+    const bool inside = h0 >= 0 && w0 >= 0 && h0 + 2 < g.H && w0 + 3 < g.W;
+    if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
+      const u32x4* p0 = img + ((int64_t)h0 * g.W + w0) * C16;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) a[r][s_] = p0[(r * g.W + s_) * C16] ^ xw;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          const int h = h0 + r, ww = w0 + s_;
+          const bool ok = h >= 0 && h < g.H && ww >= 0 && ww < g.W;
+          const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = ww < 0 ? 0 : (ww >= g.W ? g.W - 1 : ww);
+          const u32x4 v = img[((int64_t)hc * g.W + wc) * C16];
+          a[r][s_] = (ok ? v : u32x4{zpw, zpw, zpw, zpw}) ^ xw;
+        }
+    }
+    const int c = c16 * 16;
+    const int64_t pixA = ((int64_t)n * g.P + p) * g.Q + q;
+    uint32_t codesA[4], codesB[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      uint32_t Rw[3][4];        // Rw[r][j]: columns w0 .. w0+3 of channel c + 4d + j in row r
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const uint32_t l01 = __builtin_amdgcn_perm(a[r][1][d], a[r][0][d], 0x05010400u), h01 = __builtin_amdgcn_perm(a[r][1][d], a[r][0][d], 0x07030602u);
+        const uint32_t l23 = __builtin_amdgcn_perm(a[r][3][d], a[r][2][d], 0x05010400u), h23 = __builtin_amdgcn_perm(a[r][3][d], a[r][2][d], 0x07030602u);
+        Rw[r][0] = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
+        Rw[r][1] = __builtin_amdgcn_perm(l23, l01, 0x07060302u);
+        Rw[r][2] = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
+        Rw[r][3] = __builtin_amdgcn_perm(h23, h01, 0x07060302u);
+      }
+      f32x4 vA, vB;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 ta = tabA[(d * 4 + j) * C16 + c16];
+        const u32x4 tb = tabB[(d * 4 + j) * C16 + c16];
+        const f32x4 tp = tabp[(d * 4 + j) * C16 + c16];
+        int sA = __builtin_amdgcn_sdot4((int)Rw[0][j], (int)ta.x, (int)ta.w, false);
+        sA = __builtin_amdgcn_sdot4((int)Rw[1][j], (int)ta.y, sA, false);
+        sA = __builtin_amdgcn_sdot4((int)Rw[2][j], (int)ta.z, sA, false);
+        int sB = __builtin_amdgcn_sdot4((int)Rw[0][j], (int)tb.x, (int)ta.w, false);
+        sB = __builtin_amdgcn_sdot4((int)Rw[1][j], (int)tb.y, sB, false);
+        sB = __builtin_amdgcn_sdot4((int)Rw[2][j], (int)tb.z, sB, false);
+        float rA = (float)sA * tp.x, rB = (float)sB * tp.x;        // S1 = SUM (q - zp) * qw, exact
+        if (asym) {
+          int zA = __builtin_amdgcn_sdot4((int)Rw[0][j], 0x00010101, 9 * dz, false);
+          zA = __builtin_amdgcn_sdot4((int)Rw[1][j], 0x00010101, zA, false);
+          zA = __builtin_amdgcn_sdot4((int)Rw[2][j], 0x00010101, zA, false);
+          int zB = __builtin_amdgcn_sdot4((int)Rw[0][j], 0x01010100, 9 * dz, false);
+          zB = __builtin_amdgcn_sdot4((int)Rw[1][j], 0x01010100, zB, false);
+          zB = __builtin_amdgcn_sdot4((int)Rw[2][j], 0x01010100, zB, false);
+          rA = rA + (float)zA * tp.y;                                // S0 = SUM (q - zp)
+          rB = rB + (float)zB * tp.y;
+        }
+        if (bias) {
+          rA = rA + tp.z;
+          rB = rB + tp.z;
+        }
+        vA[j] = rA;
+        vB[j] = rB;
+      }
+      if (ep.relu && !fold) {
+        vA = f32x4{relu_nan(vA.x), relu_nan(vA.y), relu_nan(vA.z), relu_nan(vA.w)};
+        vB = f32x4{relu_nan(vB.x), relu_nan(vB.y), relu_nan(vB.z), relu_nan(vB.w)};
+      }
+      const int64_t at = pixA * C + c + d * 4;
+      if (out) {
+        __builtin_nontemporal_store(vA, reinterpret_cast<f32x4*>(out + at));
+        if (hasB) __builtin_nontemporal_store(vB, reinterpret_cast<f32x4*>(out + at + C));
+      }
+      if (ep.codes) {
+        codesA[d] = eq.code4(vA);
+        codesB[d] = eq.code4(vB);
+      }
+    }
+    if (ep.codes) {
+      __builtin_nontemporal_store(u32x4{codesA[0], codesA[1], codesA[2], codesA[3]}, reinterpret_cast<u32x4*>(ep.codes + pixA * C + c));
+      if (hasB)
+        __builtin_nontemporal_store(u32x4{codesB[0], codesB[1], codesB[2], codesB[3]}, reinterpret_cast<u32x4*>(ep.codes + (pixA + 1) * C + c));
+    }
+  }
+}
+
 // Any R, S <= 7 and C % 4 == 0: one dword of codes per thread and tap.
 __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw_i8_kernel(const uint32_t* __restrict__ x, const uint32_t* __restrict__ w,
                                                                 float* __restrict__ out, const float* __restrict__ bias,
@@ -247,7 +389,15 @@ extern "C" int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* ou
   const int64_t blocks = (total + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool wide = R == 3 && S == 3 && C % 16 == 0 && C <= 2048 && aligned16(x) && (!codes || aligned16(codes));
-  if (wide) {
+  if (wide && stride == 1 && pad == 1 && C <= 1024) {     // two output pixels per thread (LDS: 48 B per channel)
+    g.cdiv = make_fastdiv((uint32_t)(C / 16));
+    const int64_t qpairs = (Q + 1) / 2;
+    g.qdiv = make_fastdiv((uint32_t)qpairs);
+    const int64_t b16 = (N * P * qpairs * (C / 16) + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
+    hipLaunchKernelGGL(conv_dw3p2_i8_kernel, dim3((uint32_t)(b16 < 4096 ? b16 : 4096)), dim3(DLMCQ_BLOCK), (size_t)C * 48, st,
+                       static_cast<const u32x4*>(x), w, out, bias, in_scale, in_zero_point, w_scale, w_offset, g,
+                       x_is_unsigned ? 0 : 1, ep);
+  } else if (wide) {
     g.cdiv = make_fastdiv((uint32_t)(C / 16));
     const int64_t b16 = (N * P * Q * (C / 16) + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
     // every workgroup packs the layer's weights into its LDS table first: a grid of a few workgroups per CU, each walking many pixels

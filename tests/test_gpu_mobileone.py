@@ -110,7 +110,11 @@ def test_depthwise_kernel_shapes_and_forms():
     from dlmc.quantization.scalar import kernels as K
     import torch.nn.functional as F
     for idx, (n, c, h, w, r, stride, pad, signed, asym) in enumerate([(2, 64, 9, 9, 3, 1, 1, False, True), (3, 8, 12, 7, 3, 2, 1, False, False),
-                                                                      (1, 192, 14, 14, 5, 1, 2, True, True), (2, 12, 6, 6, 3, 1, 0, False, True)]):
+                                                                      (1, 192, 14, 14, 5, 1, 2, True, True), (2, 12, 6, 6, 3, 1, 0, False, True),
+                                                                      # the two-pixels-per-thread kernel (3x3, stride 1, padding 1, C % 16 == 0):
+                                                                      # even / odd widths, a single column, signed codes, one row
+                                                                      (1, 128, 5, 6, 3, 1, 1, False, False), (2, 32, 3, 1, 3, 1, 1, True, True),
+                                                                      (3, 16, 1, 7, 3, 1, 1, False, True), (1, 96 + 16, 28, 28, 3, 1, 1, False, True)]):
         g = torch.Generator().manual_seed(40 + idx)
         lo, hi = (-127, 127) if signed else (0, 255)
         codes = torch.randint(lo, hi + 1, (n, c, h, w), generator=g).to(torch.int8 if signed else torch.uint8)
@@ -131,6 +135,11 @@ def test_depthwise_kernel_shapes_and_forms():
         close(out.cpu(), ref, mag, f"dw case {idx}")
         from oracle import fakequant_oracle as O
         assert torch.equal(oc.cpu().float(), O.fq_zeropoint(out.cpu(), emit.scale.cpu(), emit.zero_point.cpu(), 0, 255)[0]), f"dw case {idx} codes"
+        # codes only (the ReLU folded into the quantiser's clamp): the same bytes
+        none, oc2 = K.conv2d_dw_i8(codes.to(DEV).contiguous(memory_format=torch.channels_last), qw[:, 0].permute(1, 2, 0).contiguous().to(torch.int8).to(DEV),
+                                   bias.to(DEV), torch.tensor([s_in], device=DEV), torch.tensor([zp], device=DEV), s_w.to(DEV),
+                                   None if o_w is None else o_w.to(DEV), stride=stride, padding=pad, relu=True, emit=emit, want_out=False)
+        assert none is None and torch.equal(oc2, oc), f"dw case {idx} codes-only"
 
 
 @pytest.mark.parametrize("c,k,r,stride,pad", [(3, 64, 3, 2, 1), (1, 32, 5, 1, 2), (4, 96, 7, 2, 3), (2, 8, 1, 1, 0)])
