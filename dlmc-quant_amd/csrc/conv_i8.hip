@@ -49,7 +49,7 @@ namespace dlmcq {
 //     quantiser's clamp, per-channel constants by broadcast ds_read_b128.  ~10 vector instructions per output element instead
 //     of ~20; the code tile (1 B per element) goes through LDS once so that the stores are whole rows.
 template <int BN, bool DUAL, bool ADIR, bool ASYM = false, int LAB = 0, bool SWAP = false>
-__global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : (ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
+__global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : (SWAP && BN == 64 && ADIR && !ASYM ? 5 : ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ bias,
     const int32_t* __restrict__ wsum, const float* __restrict__ s_in, const float* __restrict__ zp_in,
     const float* __restrict__ s_w, ConvGeom g, int shift, ConvEpi ep, ConvSeg2 sg) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
   constexpr int BI = BN / 64;           // B DMA wave-instructions per wave per step
   constexpr int NA = ADIR ? 1 : AI;     // A rows this lane addresses: its own fragment row (ADIR) or its DMA rows
   constexpr int EP_LD = 68;             // floats per staged epilogue row (64 + 4 pad)
-  constexpr int EP_BYTES = 4 * 32 * EP_LD * 4;
+  constexpr int EP_BYTES = SWAP ? 4 * 32 * (BN + 16) : 4 * 32 * EP_LD * 4;   // (swapped kernels stage 1-byte codes, not fp32 values)
   constexpr int LDS_BYTES = NBUF * TILE < EP_BYTES ? EP_BYTES : NBUF * TILE;   // the epilogue stage re-uses the ring
   constexpr int NH = NT / 2 + (NT & 1); // epilogue passes of 64 channels
   constexpr bool EARLY_RES = NH == 1;   // the whole shortcut tile is one pass: request it before the operands
