@@ -14,8 +14,8 @@
 //   output       fp32  NHWC   - lanes of an accumulator register hold 32 consecutive channels: 128-B stores
 // Implicit GEMM: M = N*P*Q output pixels, N = K output channels, K = R*S*C.  At ResNet sizes with fp32 outputs
 // this kernel is HBM-bound (4 B written per MAC-row vs 1 B read), so the structure favours streaming: BM = 128
-// pixels x BN in {64, 128} channels per workgroup, 4 waves (one 32-row slab each), BK = 64, double-buffered LDS
-// with register staging (one barrier per K step), rows padded to 80 B so ds_read_b128 fragments are conflict-free.
+// pixels x BN in {64, 128, 256} channels per workgroup (256: codes-only layers), 4 waves (one 32-row slab each), BK = 64,
+// a 3-slot LDS ring fed by LDS-DMA (one barrier per K step, XOR-swizzled 64-byte rows: see the kernel).
 #include <cstdlib>
 #include <type_traits>
 
