@@ -228,7 +228,7 @@ def test_conv_i8_random_shapes_against_float64():
 
 def test_codes_only_epilogue_random_shapes_match_the_two_pass_path():
     """Layers that emit only their consumer's codes run in the swapped accumulator layout (conv_i8_mfma_kernel<..., SWAP>: a lane
-    owns 16 channels of one pixel, the ReLU is folded into the quantiser's clamp).  80 random geometries - widths that do and do
+    owns 16 channels of one pixel, the ReLU is folded into the quantiser's clamp).  4 fixed (the 256-wide tile rule) + 80 random geometries - widths that do and do
     not qualify (K % tile width), ragged row tiles, all four quantiser forms incl. signed ranges and non-zero offsets, ReLU on and
     off, bias on and off, symmetric and asymmetric weights - against the same convolution's fp32 output put through ReLU and the
     stand-alone fake-quant kernel: the codes must be the same bytes."""
@@ -239,10 +239,14 @@ def test_codes_only_epilogue_random_shapes_match_the_two_pass_path():
     def ri(lo, hi):
         return int(torch.randint(lo, hi + 1, (1,), generator=g))
     forms = [N.FORM_ZEROPOINT, N.FORM_SYMMETRIC, N.FORM_EMULATE, N.FORM_QBASE]
+    # the shapes whose tile rule is the 256-wide swapped kernel (A direct / A through the ring) come first, then random ones
+    fixed = [(2, 512, 512, 3), (3, 2048, 512, 1), (1, 512, 256, 3), (2, 1024, 256, 1)]
     done = 0
-    while done < 80:
+    while done < 84:
         n, c, k = ri(1, 3), 64 * ri(1, 3), [64, 128, 192, 256, 72, 32][ri(0, 5)]
         r = [1, 3][ri(0, 1)]
+        if done < len(fixed):
+            n, c, k, r = fixed[done]
         stride, pad = ri(1, 2), ri(0, 1)
         h, w = ri(2, 13), ri(2, 13)
         p, q = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - r) // stride + 1
