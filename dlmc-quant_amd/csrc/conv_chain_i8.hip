@@ -180,6 +180,12 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   for (int g = 0; g < 4; ++g) {
     const int lr = wr * 32 + 8 * g + 4 * hsel + b4;
     fo[g] = lr < rows_here ? (int)(((row0 + lr) * a.KD + wc * 32 + q4 * 4) * 4) : CH_BIG;
+#ifdef DLMCQ_LAB
+    if (a.lab & 4) {   // timing only: the access pattern a 16 x 16 x 64 accumulator layout would have - 16 rows x 64 bytes per instruction
+      const int lr2 = wr * 32 + 16 * (g >> 1) + 2 * (4 * hsel + b4) + (q4 >> 2);
+      fo[g] = lr2 < rows_here ? (int)(((row0 + lr2) * a.KD + wc * 32 + 16 * (g & 1) + (q4 & 3) * 4) * 4) : CH_BIG;
+    }
+#endif
   }
   const int nst = (a.out ? 4 : 0) + (a.codes ? 1 : 0);   // stores per wave per chunk
 
