@@ -185,6 +185,10 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
       const int lr2 = wr * 32 + 16 * (g >> 1) + 2 * (4 * hsel + b4) + (q4 >> 2);
       fo[g] = lr2 < rows_here ? (int)(((row0 + lr2) * a.KD + wc * 32 + 16 * (g & 1) + (q4 & 3) * 4) * 4) : CH_BIG;
     }
+    if (a.lab & 8) {   // timing only: 4 rows x 256 bytes per instruction (a wave owning 16 rows x 64 channels)
+      const int lr3 = wr * 32 + wc * 16 + 4 * g + (lane >> 4);
+      fo[g] = lr3 < rows_here ? (int)(((row0 + lr3) * a.KD + (lane & 15) * 4) * 4) : CH_BIG;
+    }
 #endif
   }
   const int nst = (a.out ? 4 : 0) + (a.codes ? 1 : 0);   // stores per wave per chunk

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--cases", default=",".join(CASES))
     ap.add_argument("--rows", default="0")
     ap.add_argument("--iters", type=int, default=6)
-    ap.add_argument("--lab", default="", help="lab library flags to time as extra variants, e.g. 1,2,noout (1 = no shortcut loads, 4 = fp32 accesses as 16 rows x 64 bytes per instruction; timing only)")
+    ap.add_argument("--lab", default="", help="lab library flags to time as extra variants, e.g. 1,2,noout (1 = no shortcut loads, 4 / 8 = fp32 accesses as 16 rows x 64 bytes / 4 rows x 256 bytes per instruction; timing only)")
     args = ap.parse_args()
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(11)
