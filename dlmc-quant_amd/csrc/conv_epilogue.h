@@ -99,10 +99,14 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
   __device__ __forceinline__ uint32_t exact4(const f32x4& v, uint32_t wfast) const {
     const float t0 = __builtin_fmaf(v.x - of, rdv, zadd), t1 = __builtin_fmaf(v.y - of, rdv, zadd);
     const float t2 = __builtin_fmaf(v.z - of, rdv, zadd), t3 = __builtin_fmaf(v.w - of, rdv, zadd);
-    uint32_t m = (!(__builtin_fabsf(t0 - __builtin_rintf(t0)) < TIE_THR) ? 1u : 0u) |
-                 (!(__builtin_fabsf(t1 - __builtin_rintf(t1)) < TIE_THR) ? 2u : 0u) |
-                 (!(__builtin_fabsf(t2 - __builtin_rintf(t2)) < TIE_THR) ? 4u : 0u) |
-                 (!(__builtin_fabsf(t3 - __builtin_rintf(t3)) < TIE_THR) ? 8u : 0u);
+    // Second look, by magnitude: |t - (d + zadd)| <= 2^-23 |q| + 2^-24 |t| with |q| <= |t| + 256.5, i.e. < 2^-24 (3 |t| + 514), which
+    // is below 2^-22 (|t| + 256) for every finite t - no saturation argument needed.  The fast path's fixed margin (2^-13) is
+    // that bound at |t| = 768; an element of ordinary size sits ~16x closer to a tie before it really needs the division,
+    // so most entries into this branch end here, with the fast bytes confirmed.
+    auto near_tie = [](float t) {
+      return !(__builtin_fabsf(t - __builtin_rintf(t)) < 0.5f - (__builtin_fabsf(t) + 256.0f) * 0x1p-22f);
+    };
+    uint32_t m = (near_tie(t0) ? 1u : 0u) | (near_tie(t1) ? 2u : 0u) | (near_tie(t2) ? 4u : 0u) | (near_tie(t3) ? 8u : 0u);
     uint32_t w = wfast;
 #pragma unroll 1
     while (m) {
