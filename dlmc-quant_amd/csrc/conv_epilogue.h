@@ -52,8 +52,11 @@ __device__ __forceinline__ f32x4 relu4_nan(const f32x4& y) {
 }
 
 struct EpiQuant {   // the consumer's constants, resolved once per thread
-  // |t - tie| must reach this for the fast path to stand (see code4_fast: the bound on |t - (d + zadd)| is 1.75 * 2^-14)
-  static constexpr float TIE_THR = 0.5f - 0x1p-13f;
+  // |t - rint(t)| must stay below this for the fast path to stand (see code4_fast): 0.5 minus the bound on |t - (d + zadd)| at
+  // the largest code that does not saturate.  With A = max(|lo|, |hi|) + 0.5: |q| <= A + |zadd|, |t| <= A + 2^-13, so the bound is
+  // 2^-24 (2 (A + |zadd|) + A) - for an unsigned 8-bit quantiser with zero point 0 (every post-ReLU tensor) 0.37 * 2^-13, at the
+  // extremes the ABI allows (|zadd| = 256, A = 255.5) 1.75 * 2^-14 < 2^-13.
+  float tie_thr;
   float dv, rdv, of, zadd, lo, hi;
   float lo_fast;    // lower clamp of the fast path: `lo`, or max(lo, code of 0) when the ReLU is folded into the quantiser
   int form;
@@ -61,7 +64,7 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
   // fold_relu: the caller quantises relu(v) but passes v: every form is monotone, so code(relu(v)) = max(code(v), code(0))
   // for a finite v - one clamp bound instead of a compare + select per element (NaN takes the exact path, which rectifies)
   __device__ __forceinline__ EpiQuant(const ConvEpi& ep, bool fold_relu = false)
-      : dv(1.0f), rdv(1.0f), of(0.0f), zadd(0.0f), lo(ep.q_lo), hi(ep.q_hi), lo_fast(ep.q_lo), form(ep.q_form),
+      : tie_thr(0.5f - 0x1p-13f), dv(1.0f), rdv(1.0f), of(0.0f), zadd(0.0f), lo(ep.q_lo), hi(ep.q_hi), lo_fast(ep.q_lo), form(ep.q_form),
         sgn(ep.q_lo < 0.0f), fold(fold_relu) {
     if (!ep.codes) return;
     const float s = ep.q_scale[0];
@@ -75,6 +78,10 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
     const bool tame = __builtin_fabsf(dv) >= 0x1p-100f && __builtin_fabsf(dv) <= 0x1p100f && __builtin_fabsf(zadd) <= 256.0f &&
                       zadd == __builtin_rintf(zadd);
     rdv = tame ? 1.0f / dv : __builtin_nanf("");
+    {
+      const float A = (__builtin_fabsf(lo) > __builtin_fabsf(hi) ? __builtin_fabsf(lo) : __builtin_fabsf(hi)) + 0.5f;
+      tie_thr = 0.5f - (3.0f * A + 2.0f * __builtin_fabsf(zadd) + 4.0f) * 0x1p-24f;     // (+ 4: slack for the roundings of this line)
+    }
     if (fold) {
       const float q0 = exact_q(0.0f);
       lo_fast = q0 > lo ? q0 : lo;     // (a NaN code of 0 - NaN scale - keeps lo; rdv is NaN then and nothing takes the fast path)
@@ -124,9 +131,11 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
   // A correctly rounded division costs ~25 VALU operations per element - more than everything else in the epilogue -
   // so d is replaced by t = fl(u * fl(1/dv) + zadd) (one fma).  With q = u/dv: |u fl(1/dv) - q| <= 2^-24 |q|, the fma rounds by
   // <= 2^-24 |t|, and |d - q| <= 2^-24 |q|, so |t - (d + zadd)| <= 2^-23 |q| + 2^-24 |t|.  A code that does not saturate has
-  // |q| <= 512 and |t| <= 768 (|zadd| <= 256, |lo|, |hi| <= 255): the difference is below 1.75 * 2^-14 < 2^-13, so unless t lies
-  // within 2^-13 of a rounding tie (x.5), rint(t) = rint(d) + zadd; beyond that range both saturate to the same bound.  Ties
-  // that close, infinities and NaNs (about one element in 4000) take the exact division, element by element (exact4).
+  // |t| <= A = max(|lo|, |hi|) + 0.5 and |q| <= A + |zadd|: the difference is below 2^-24 (3 A + 2 |zadd|) =: M (`tie_thr` = 0.5 - M;
+  // at most 1.75 * 2^-14), so unless t lies within M of a rounding tie (x.5), rint(t) = rint(d) + zadd.  Beyond |t| = A the
+  // difference may exceed M, but it stays below 0.2 up to |t| = 2^20 and both values are then past the same clamp bound by
+  // more than 0.3: both saturate to it (and further out a fortiori).  Ties that close, infinities and NaNs (about one element
+  // in 10 000 for an unsigned byte with zero point 0) go to exact4: a second, magnitude-aware look, then the exact division.
   // Bit-identical codes at ~6 operations per element: the
   // block-end layers are bound by the VALU instructions of their epilogue (tools/chain_trace.py), so the arithmetic
   // is written on pairs (v_pk_add_f32 / v_pk_mul_f32: two elements per instruction, same roundings), and a non-finite
@@ -135,7 +144,7 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
   // Callers with several independent quads evaluate them all, OR the flags and branch ONCE: a branch per quad chains
   // the quads one behind the other (each ~25 dependent instructions long), which is what bounded the block-end layers.
   // The zero point rides on the multiply: t = fma(u, 1/dv, zadd) (zadd is integral, checked above), q = rint(t).  t differs
-  // from d + zadd by less than 2^-13 in the range that does not saturate (above), so the tie test is applied to t itself: 6 instructions per element (fma, rint, sub, compare, clamp, pack)
+  // from d + zadd by less than M in the range that does not saturate (above), so the tie test is applied to t itself: 6 instructions per element (fma, rint, sub, compare, clamp, pack)
   // when the form has no offset to subtract first (OFZ).
   template <bool OFZ>
   __device__ __forceinline__ uint32_t code4_fast(const f32x4& v, bool& unsure) const {
@@ -143,7 +152,7 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
     const float t0 = __builtin_fmaf(u0, rdv, zadd), t1 = __builtin_fmaf(u1, rdv, zadd), t2 = __builtin_fmaf(u2, rdv, zadd),
                 t3 = __builtin_fmaf(u3, rdv, zadd);
     const float r0 = __builtin_rintf(t0), r1 = __builtin_rintf(t1), r2 = __builtin_rintf(t2), r3 = __builtin_rintf(t3);
-    constexpr float thr = TIE_THR;
+    const float thr = tie_thr;
     unsure = !(__builtin_fabsf(t0 - r0) < thr) | !(__builtin_fabsf(t1 - r1) < thr) | !(__builtin_fabsf(t2 - r2) < thr) |
              !(__builtin_fabsf(t3 - r3) < thr);
     float q0 = __builtin_amdgcn_fmed3f(r0, lo_fast, hi), q1 = __builtin_amdgcn_fmed3f(r1, lo_fast, hi);
