@@ -49,7 +49,7 @@ namespace dlmcq {
 //     quantiser's clamp, per-channel constants by broadcast ds_read_b128.  ~10 vector instructions per output element instead
 //     of ~20; the code tile (1 B per element) goes through LDS once so that the stores are whole rows.
 template <int BN, bool DUAL, bool ADIR, bool ASYM = false, int LAB = 0, bool SWAP = false>
-__global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : (SWAP && BN == 64 && ADIR && !ASYM ? 5 : ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
+__global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : (SWAP && BN == 64 && ADIR && !ASYM ? 5 : SWAP && BN == 128 && ADIR && !ASYM ? 3 : ADIR || BN == 64 ? (ASYM ? 3 : 4) : 3))) void conv_i8_mfma_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ bias,
     const int32_t* __restrict__ wsum, const float* __restrict__ s_in, const float* __restrict__ zp_in,
     const float* __restrict__ s_w, ConvGeom g, int shift, ConvEpi ep, ConvSeg2 sg) {
