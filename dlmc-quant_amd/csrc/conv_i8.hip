@@ -53,7 +53,11 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ bias,
     const int32_t* __restrict__ wsum, const float* __restrict__ s_in, const float* __restrict__ zp_in,
     const float* __restrict__ s_w, ConvGeom g, int shift, ConvEpi ep, ConvSeg2 sg) {
-  constexpr int BM = CV_BM, BK = CV_BK, NBUF = 3, PF = NBUF - 1;
+#ifndef DLMCQ_NB_SWAP128
+#define DLMCQ_NB_SWAP128 3
+#endif
+  // ring depth: 3 slots (two K steps in flight); A/B hook for the 128-wide A-direct swapped kernel, whose LDS and registers leave room for more
+  constexpr int BM = CV_BM, BK = CV_BK, NBUF = (SWAP && BN == 128 && ADIR && !ASYM) ? DLMCQ_NB_SWAP128 : 3, PF = NBUF - 1;
   // LAB (lab library only): 1 = clock stamps; 2 = no A loads, 3 = no B loads, 4 = no MFMAs, 5 = all lanes load one A address
   // (what-bounds-the-step experiments: results are garbage, only the time means something)
   constexpr bool STAMP = LAB == 1;
@@ -282,12 +286,11 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
     constexpr int U = decltype(slot_c)::value;          // ring slot of this step; step + PF goes to slot (U + PF) % NBUF
     stamp(step, 0);
     // step's own loads must have landed; the younger group stays in flight
-    if (step + PF - 1 < nsteps) {
-      static_assert(PF == 2, "vmcnt immediates below");
-      if (GROUP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else if (GROUP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (GROUP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert((PF - 1) * GROUP <= 63, "vmcnt is a 6-bit count");
+    if (step + PF - 1 < nsteps) {                  // PF - 1 younger steps stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * GROUP) : "memory");
+    } else if (PF > 2 && step + 1 < nsteps) {      // (deeper rings, near the end: at least one younger step)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GROUP) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last step
     }
