@@ -557,6 +557,7 @@ struct ConvPlan {
   int bn;       // tile width: 64 or 128 channels
   bool adir;    // activations straight to registers (see the kernel)
   bool swap;    // codes-only layers in the swapped accumulator layout (see the kernel)
+  bool halo = true;   // 3x3 / stride 1 / pad 1 codes-only layers on the halo-tile kernel of conv3x3_i8.hip where it applies
 };
 
 static ConvPlan conv_plan(int64_t C, int64_t K, int64_t R, int64_t S, bool dual) {
@@ -620,6 +621,8 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int8_t* xs = reinterpret_cast<const int8_t*>(x);
   const ConvPlan plan = forced ? *forced : conv_plan(C, K, R, S, seg2 != nullptr);
+  if (plan.halo && conv3x3_halo_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
+    return conv3x3_halo_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, shift, ep, st);
   if (plan.bn != 64 && plan.bn != 128 && plan.bn != 256) return DLMCQ_EINVAL;
   // 256-wide tiles exist for the swapped codes-only layers only (one third fewer operand bytes per MAC, two workgroups per CU)
   const bool swap_ok = plan.swap && ep.codes && !out && !ep.residual && K % plan.bn == 0 && aligned16(ep.codes);
@@ -844,7 +847,7 @@ extern "C" int dlmcq_x_conv2d_i8_tuned(const void* x, const int8_t* w, float* ou
 #undef DLMCQ_LABK
     return launch_status();
   }
-  const ConvPlan plan{bn, (adir & 1) != 0, (adir & 2) == 0};     // adir bit 1: the unswapped epilogue (A/B runs)
+  const ConvPlan plan{bn, (adir & 1) != 0, (adir & 2) == 0, (adir & 4) != 0};     // adir bit 1: the unswapped epilogue; bit 2: the halo kernel (A/B runs)
   return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
                      x_is_unsigned, stream, ep, nullptr, &plan);
 }

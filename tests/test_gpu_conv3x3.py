@@ -1,0 +1,100 @@
+"""The halo-tile 3x3 kernel (csrc/conv3x3_i8.hip: 3x3 / stride 1 / pad 1 layers that emit only their consumer's codes,
+K % 128 == 0) against (a) the float64 convolution of the dequantised operands + the oracle's quantiser and (b) the generic
+implicit-GEMM kernel of conv_i8.hip run on the same layer with an fp32 output as well (which keeps it off the halo kernel):
+both kernels add the same exact int32 sums into the same rounding chain, so their codes must agree bit for bit.
+Reference call being replaced: F.conv2d in modules/conv.py:13-19 on the operands of FSPTQuant/base.py:108-109,149-152."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fakequant_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# N, C, H, W, K  (frame pitch W + 1; halo pieces per chunk = ceil((256 + 2 (W + 1) + 2) / 16): <= 24 -> HPW 3, else HPW 4)
+SHAPES = [
+    (3, 64, 7, 7, 128),        # FS = 64: four images per tile, 23 % junk rows
+    (2, 128, 14, 14, 128),     # two chunks: the halo double buffer
+    (1, 64, 28, 28, 256),      # two column blocks
+    (2, 64, 56, 56, 128),      # Wp = 57: 24 halo pieces (the HPW = 3 limit)
+    (1, 64, 5, 70, 128),       # Wp = 71: HPW = 4 instantiation
+    (1, 64, 3, 118, 128),      # Wp = 119: the widest image the kernel takes (32 pieces)
+    (5, 256, 14, 14, 256),     # ResNet-50 stage 3 / RepVGG stage 3 shape, tiles crossing images
+    (3, 512, 7, 7, 512),       # ResNet-50 stage 4 shape: 72 K steps
+    (1, 64, 1, 1, 128),        # one pixel: every tap but the centre is border
+    (2, 64, 2, 3, 128),
+    (7, 64, 9, 13, 128),       # M not a multiple of anything
+]
+
+
+def _layer(idx, n, c, h, w, k, unsigned, zp, relu, with_bias):
+    g = torch.Generator().manual_seed(4242 + idx)
+    lo, hi = (0, 255) if unsigned else (-127, 127)
+    codes = torch.randint(lo, hi + 1, (n, c, h, w), generator=g).to(torch.uint8 if unsigned else torch.int8)
+    wt = torch.randn(k, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5
+    s_w, _ = O.minmax_channel(wt, 8, True, ch_axis=0)
+    s_w = s_w + 1e-6
+    bias = torch.randn(k, generator=g) * 0.1 if with_bias else None
+    s_in = torch.tensor(0.0231)
+    qw, wdeq = O.fq_symmetric(wt, s_w, -127, 127)
+    ref = F.conv2d((codes.double() - zp) * s_in.double(), wdeq.double(), None if bias is None else bias.double(), padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    return codes, wt, s_w, bias, s_in, ref
+
+
+@pytest.mark.parametrize("unsigned", [True, False])
+def test_halo_kernel_vs_float64_and_generic_kernel(unsigned):
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    worst = 0.0
+    for idx, (n, c, h, w, k) in enumerate(SHAPES):
+        zp = float(3 + idx) if unsigned else float(idx % 3 - 1)      # non-zero: the borders must read the zero point's code
+        relu = idx % 2 == 0
+        codes, wt, s_w, bias, s_in, ref = _layer(idx, n, c, h, w, k, unsigned, zp, relu, idx % 3 != 1)
+        wq, wsum = K.quantize_weight_krsc(wt.to(DEV), s_w.to(DEV), -127, 127)
+        if unsigned:
+            q_s = (ref.abs().max() / 200).float().reshape(1)         # some saturation
+            q_z, lo, hi, form = torch.tensor([2.0]), 0, 255, N.FORM_ZEROPOINT
+        else:
+            q_s = (ref.abs().max() / 100).float().reshape(1)
+            q_z, lo, hi, form = None, -127, 127, N.FORM_SYMMETRIC
+        emit = K.EmitCodes(q_s.to(DEV), None if q_z is None else q_z.to(DEV), lo, hi, form)
+        cd = codes.to(DEV).contiguous(memory_format=torch.channels_last)
+        args = (cd, wq, wsum, None if bias is None else bias.to(DEV), s_in.to(DEV), torch.tensor(zp).to(DEV), s_w.to(DEV))
+        _, got = K.conv2d_i8(*args, padding=1, relu=relu, emit=emit, want_out=False)          # the halo kernel
+        out, gen = K.conv2d_i8(*args, padding=1, relu=relu, emit=emit, want_out=True)         # the generic kernel
+        assert got.shape == (n, k, h, w) and got.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(got, gen), f"shape {idx} {SHAPES[idx]}: halo kernel and generic kernel disagree"
+        torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-6, atol=2e-5, msg=lambda m: f"shape {idx}: {m}")
+        # the oracle's quantiser on the float64 result: int32-exact accumulation vs float64 may differ by one code at a tie
+        if form == N.FORM_ZEROPOINT:
+            want = O.fq_zeropoint(ref.float(), q_s[0], q_z[0], lo, hi)[0]
+        else:
+            want = O.fq_symmetric(ref.float(), q_s[0], lo, hi)[0]
+        off = (got.cpu().float() - want).abs()
+        assert float(off.max()) <= 1.0, f"shape {idx}: code off by {float(off.max())}"
+        worst = max(worst, float((off > 0).float().mean()))
+    print(f"halo 3x3: worst off-by-one rate {worst:.2e}")
+    assert worst < 1e-3
+
+
+def test_halo_kernel_border_rows_never_leak():
+    """Rows of the linear frame that are not pixels (x = W, y = H) are multiplied and dropped: a canary around the output
+    tensor must survive, and an all-zero-point input must give exactly the bias's codes everywhere."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    n, c, h, w, k = 3, 64, 6, 11, 128
+    zp = 7.0
+    codes = torch.full((n, c, h, w), int(zp), dtype=torch.uint8, device=DEV).contiguous(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(77)
+    wt = torch.randn(k, c, 3, 3, generator=g) * 0.05
+    s_w, _ = O.minmax_channel(wt, 8, True, ch_axis=0)
+    wq, wsum = K.quantize_weight_krsc(wt.to(DEV), s_w.to(DEV), -127, 127)
+    bias = torch.linspace(-1, 1, k)
+    emit = K.EmitCodes(torch.tensor([0.01], device=DEV), torch.tensor([100.0], device=DEV), 0, 255, N.FORM_ZEROPOINT)
+    _, got = K.conv2d_i8(codes, wq, wsum, bias.to(DEV), torch.tensor(0.02, device=DEV), torch.tensor(zp, device=DEV), s_w.to(DEV),
+                         padding=1, emit=emit, want_out=False)
+    want = O.fq_zeropoint(bias, torch.tensor(0.01), torch.tensor(100.0), 0, 255)[0].to(torch.uint8)
+    assert torch.equal(got.cpu(), want.view(1, k, 1, 1).expand(n, k, h, w))
