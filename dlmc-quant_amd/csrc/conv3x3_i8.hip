@@ -18,11 +18,14 @@
 //     positions read a constant line) and the nine taps read nine shifted ds_read_b128 fragments of it: activation
 //     traffic through the vector-memory path / ~7.  The next chunk's tile lands in a second buffer meanwhile.
 //   * WEIGHTS ride a 3-slot ring, one (tap, chunk) slab of BN x 64 bytes per K step, two steps in flight, ONE raw barrier
-//     and one counted s_waitcnt vmcnt per step (as conv_i8.hip; LDS-DMA with the XOR swizzle on the source side).
+//     and one counted s_waitcnt vmcnt per step (as conv_i8.hip; LDS-DMA with the XOR swizzle on the source side); the
+//     loop is software-pipelined by half a step, so that barrier, fragment reads and DMA requests issue between MFMAs.
 //     A 256-row tile halves the slab bytes per MAC of the 128-row kernel.
-//   * 8 waves: 2 x 2 MFMA blocks each (v_mfma_i32_32x32x32_i8, weights as A, pixels as B: a lane's 16 accumulator
-//     registers of a block are 16 consecutive channels of one pixel - conv_i8.hip's swapped epilogue, ~10 vector
-//     instructions per output element); two workgroups per CU.
+//   * v_mfma_i32_32x32x32_i8 with the weights as A and the pixels as B: a lane's 16 accumulator registers of a block are 16
+//     consecutive channels of one pixel - conv_i8.hip's swapped epilogue, ~10 vector instructions per output element.
+//     Wave tiling (template): 4 waves of 64 pixels x 128 channels (2 x 4 blocks: 6 fragment reads, 16 MFMAs per K half-step;
+//     two workgroups = two INDEPENDENT waves per SIMD), or 8 waves of 64 x 64 (2 x 2 blocks; round 3's first version:
+//     its fragment reads, xors and address arithmetic per MFMA are twice as many and its two waves per SIMD run in lockstep).
 //   Vector-memory bytes per K step: 8 KB of weights + 1/9 of a ~20 KB tile for 512 clocks of matrix work per CU: ~20 B/clock.
 #include "conv_i8_common.h"
 
@@ -37,26 +40,33 @@ struct HaloGeom {
   FastDiv fsdiv, wpdiv;
 };
 
-template <int BN, int TM, int HPW>
-__global__ __launch_bounds__(512, (HPW <= 3 && TM == 256 ? 4 : 2)) void conv3x3_halo_i8_kernel(
+// LAB (lab library only; results are garbage except for 0 and 1, only the time means something): 1 = clock stamps into `trace`;
+// 2 = no weight DMA, 3 = no halo DMA, 4 = no MFMAs, 6 = no xor of the pixel fragments, 7 = no quantising epilogue,
+// 8 = codes stored straight from the accumulator layout (32-byte pieces, no staging through LDS)
+template <int BN, int TM, int NW, int WC, int HPW, int LAB = 0>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? (HPW <= 3 ? 4 : 2) : (HPW <= 6 ? 2 : 1))) void conv3x3_halo_i8_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, const float* __restrict__ bias, const int32_t* __restrict__ wsum,
-    const float* __restrict__ s_in, const float* __restrict__ zp_in, const float* __restrict__ s_w, HaloGeom g, int shift, ConvEpi ep) {
+    const float* __restrict__ s_in, const float* __restrict__ zp_in, const float* __restrict__ s_w, HaloGeom g, int shift, ConvEpi ep,
+    unsigned long long* __restrict__ trace) {
+  constexpr bool STAMP = LAB == 1;
+  const unsigned long long t_start = STAMP ? __builtin_readcyclecounter() : 0ull;
+  constexpr int NT = NW * 64;               // threads
   constexpr int NBUF = 3;
   constexpr int SLAB = BN * 64;             // one (tap, chunk) of the weights
-  constexpr int WC = BN / 64;               // waves across the channels (64 each)
-  constexpr int WPX = 8 / WC;               // waves across the pixels
+  constexpr int WPX = NW / WC;              // waves across the pixels
   constexpr int PW = TM / WPX;              // pixels per wave
-  constexpr int PB = PW / 32;               // 32-pixel MFMA blocks per wave
-  constexpr int HP = HPW * 8;               // halo pieces allocated per buffer
+  constexpr int CW = BN / WC;               // channels per wave
+  constexpr int PB = PW / 32, CB = CW / 32; // 32 x 32 MFMA blocks per wave
+  constexpr int HP = HPW * NW;              // halo pieces allocated per buffer
   constexpr int HALO = HP * 1024;
-  constexpr int BPW = SLAB / 1024;          // weight pieces per step (one per wave for BN = 128; the first BPW waves otherwise)
+  constexpr int NBW = SLAB / 1024 / NW;     // weight pieces per wave per step
   constexpr int RING = NBUF * SLAB;
   constexpr int SROW = BN + 16;             // staged code row (conflict-free 16-byte accesses)
   constexpr int STAGE = TM * SROW;
   constexpr int OPER = RING + 2 * HALO;
   constexpr int LDS_BYTES = OPER < STAGE ? STAGE : OPER;
   constexpr int PAR_BYTES = 3 * BN * 4;
-  static_assert(PB >= 1 && BPW <= 8 && (BN == 64 || BN == 128), "tile shape");
+  static_assert(PB >= 1 && CB >= 1 && NBW >= 1 && NBW * NW * 1024 == SLAB && HPW <= 8 && BN % 64 == 0, "tile shape");
   __shared__ __attribute__((aligned(1024))) int8_t lds[LDS_BYTES + PAR_BYTES];
   int8_t* const ring = lds;
   int8_t* const halo = lds + RING;
@@ -73,6 +83,18 @@ __global__ __launch_bounds__(512, (HPW <= 3 && TM == 256 ? 4 : 2)) void conv3x3_
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
   const int wc = wave % WC, wp = wave / WC;
+  // STAMP: wave 0 of every workgroup writes start / loop entered / loop left / end (+ the constant 100 MHz clock at start and end) at trace[64 * 8 + 6 * blockIdx.x],
+  // and wave 0 of the workgroup in the middle of the grid the phase boundaries of its first 64 steps at trace[step * 8 + k]
+  unsigned long long* const wgt = (STAMP && tid == 0) ? trace + 64 * 8 + 6 * (size_t)blockIdx.x : nullptr;
+  unsigned long long* const stp = (STAMP && tid == 0 && blockIdx.x == gridDim.x / 2) ? trace : nullptr;
+  if (STAMP && wgt) {
+    wgt[0] = t_start;
+    wgt[4] = __builtin_amdgcn_s_memrealtime();              // the 100 MHz constant clock: shader clock = d(memtime) / d(memrealtime) x 100 MHz
+  }
+  int stepno = 0;
+  auto stamp = [&](int k) {
+    if (STAMP && stp && stepno < 64) stp[stepno * 8 + k] = __builtin_readcyclecounter();
+  };
 
   // ---- per-channel constants of the epilogue: LDS-DMA into a table behind everything, requested first ----
   {
@@ -82,7 +104,7 @@ __global__ __launch_bounds__(512, (HPW <= 3 && TM == 256 ? 4 : 2)) void conv3x3_
       if (!arrs[a]) continue;
 #pragma unroll
       for (int c = 0; c < BN / 64; ++c) {
-        if (((a * (BN / 64) + c) & 7) != wave) continue;
+        if (((a * (BN / 64) + c) % NW) != wave) continue;
         __builtin_amdgcn_global_load_lds((gptr_t)(static_cast<const int32_t*>(arrs[a]) + n0 + c * 64 + lane),
                                          (lptr_t)(par + (a * BN + c * 64) * 4), 4, 0, 0);
       }
@@ -94,7 +116,7 @@ __global__ __launch_bounds__(512, (HPW <= 3 && TM == 256 ? 4 : 2)) void conv3x3_
   const uint32_t xorw = shift ? 0x80808080u : 0u;
   const int8_t* const padline = g_pad_table.b + ((zpi & 0xff) << 6);     // stored UNshifted: the xor happens on read
 
-  // ---- halo DMA: piece i of this wave covers halo positions (i * 8 + wave) * 16 .. + 15; LDS slot s of position p holds the
+  // ---- halo DMA: piece i of this wave covers halo positions (i * NW + wave) * 16 .. + 15; LDS slot s of position p holds the
   // logical 16-byte segment s ^ ((p >> 2) & 3) (swizzle on the source side, undone by the fragment reads) ----
   const int lrow = lane >> 2, pslot = lane & 3;
   const int8_t* hsrc[HPW];
@@ -102,7 +124,7 @@ __global__ __launch_bounds__(512, (HPW <= 3 && TM == 256 ? 4 : 2)) void conv3x3_
   int hpc[HPW];
 #pragma unroll
   for (int i = 0; i < HPW; ++i) {
-    int pc = i * 8 + wave;
+    int pc = i * NW + wave;
     pc = pc < g.hp ? pc : g.hp - 1;                                        // (surplus pieces re-load the last one: same bytes, same place)
     hpc[i] = pc;
     const int p = pc * 16 + lrow;
@@ -118,115 +140,164 @@ __global__ __launch_bounds__(512, (HPW <= 3 && TM == 256 ? 4 : 2)) void conv3x3_
   }
   auto issue_halo = [&](auto i_c, int buf) {
     constexpr int i = decltype(i_c)::value;
-    __builtin_amdgcn_global_load_lds((gptr_t)hsrc[i], (lptr_t)(halo + buf * HALO + hpc[i] * 1024), 16, 0, 0);
+    if (LAB != 3) __builtin_amdgcn_global_load_lds((gptr_t)hsrc[i], (lptr_t)(halo + buf * HALO + hpc[i] * 1024), 16, 0, 0);
     hsrc[i] += hinc[i];
   };
 
-  // ---- weight DMA: wave `wave` < BPW moves slab rows wave * 16 .. + 15 of every step; slab row d of a 32-row block holds channel
-  // 16 ((d >> 2) & 1) + 4 (d >> 3) + (d & 3), which makes a lane's 16 accumulator registers 16 consecutive channels ----
-  const bool wload = BPW == 8 || wave < BPW;
-  const int8_t* wsrc;
-  {
-    const int drow = (wave % BPW) * 16 + lrow, d = drow & 31;
+  // ---- weight DMA: piece j of this wave moves slab rows (j * NW + wave) * 16 .. + 15 of every step; slab row d of a 32-row block
+  // holds channel 16 ((d >> 2) & 1) + 4 (d >> 3) + (d & 3), which makes a lane's 16 accumulator registers 16 consecutive channels ----
+  const int8_t* wsrc[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    const int drow = (j * NW + wave) * 16 + lrow, d = drow & 31;
     const int k = n0 + (drow & ~31) + 16 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3);
-    wsrc = w + (int64_t)k * (9 * g.C) + (pslot ^ ((drow >> 2) & 3)) * 16;
+    wsrc[j] = w + (int64_t)k * (9 * g.C) + (pslot ^ ((drow >> 2) & 3)) * 16;
   }
   const int nchunks = g.C >> 6;
   const int w_tap = g.C;                       // next tap, same chunk
   const int w_chunk = 64 - 8 * g.C;            // tap 8 of chunk c -> tap 0 of chunk c + 1
   auto issue_w = [&](auto slot_c, int inc) {
     constexpr int SL = decltype(slot_c)::value;
-    if (wload) __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(ring + SL * SLAB + (wave % BPW) * 1024), 16, 0, 0);
-    wsrc += inc;
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      if (LAB != 2) __builtin_amdgcn_global_load_lds((gptr_t)wsrc[j], (lptr_t)(ring + SL * SLAB + (j * NW + wave) * 1024), 16, 0, 0);
+      wsrc[j] += inc;
+    }
   };
 
   // ---- fragment addresses ----
-  // weights (MFMA A): rows wc * 64 + jc * 32 + l31 of the slab; the two K halves of a step are slots (ks * 2 + hsel) ^ swz
+  // weights (MFMA A): rows wc * CW + jc * 32 + l31 of the slab (the swizzle term (d >> 2) & 3 does not depend on jc); the two
+  // K halves of a step are slots (ks * 2 + hsel) ^ swz
   int woff[2];
-#pragma unroll
-  for (int jc = 0; jc < 2; ++jc) {
-    const int d = wc * 64 + jc * 32 + l31;
-    woff[jc] = d * 64 + ((hsel ^ ((d >> 2) & 3)) << 4);
+  {
+    const int d = wc * CW + l31;
+    woff[0] = d * 64 + ((hsel ^ ((d >> 2) & 3)) << 4);
+    woff[1] = woff[0] ^ 32;
   }
   const int pbase = wp * PW + l31;             // this lane's pixel row of block 0 (halo position of tap (0, 0))
   const int tap_r1 = g.Wp, tap_r2 = 2 * g.Wp;
 
-  i32x16 acc[2][PB];
+  i32x16 acc[CB][PB];
 #pragma unroll
-  for (int jc = 0; jc < 2; ++jc)
+  for (int jc = 0; jc < CB; ++jc)
 #pragma unroll
     for (int jp = 0; jp < PB; ++jp)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[jc][jp][i] = 0;
 
-  // ---- prologue: chunk 0's tile, the first two slabs ----
+  // ---- the K loop, software-pipelined by half a step.  Fragment set A holds K half 0 of a step, set B half 1.  Step s:
+  //   phase 0:  read B(s);                                   8 MFMAs on A(s)
+  //   phase 1:  wait for slab s + 1, barrier, read A(s + 1), request slab s + 3 (+ a piece of the next chunk's tile);
+  //             8 MFMAs on B(s)
+  // so every LDS read, DMA request and barrier is issued between MFMAs that are already fed. ----
+  i32x4 wfA[CB], pfA[PB], wfB[CB], pfB[PB];
+  auto read_frags = [&](auto u_c, auto t_c, auto ks_c, const int8_t* hbuf, i32x4 (&wf)[CB], i32x4 (&pf)[PB]) {
+    constexpr int U = decltype(u_c)::value, t = decltype(t_c)::value, ks = decltype(ks_c)::value;
+    constexpr int r = t / 3, s = t % 3;
+    const int p0 = pbase + (r == 0 ? 0 : (r == 1 ? tap_r1 : tap_r2)) + s;
+    const int pa = (p0 * 64 + ((hsel ^ ((p0 >> 2) & 3)) << 4)) ^ (ks << 5);     // ((p + 32 jp) >> 2) & 3 = (p >> 2) & 3
+    const int8_t* const sb = ring + U * SLAB;
+#pragma unroll
+    for (int jc = 0; jc < CB; ++jc) wf[jc] = *reinterpret_cast<const i32x4*>(sb + woff[ks] + jc * 2048);
+#pragma unroll
+    for (int jp = 0; jp < PB; ++jp) pf[jp] = *reinterpret_cast<const i32x4*>(hbuf + pa + jp * 2048);
+  };
+  auto multiply = [&](const i32x4 (&wf)[CB], i32x4 (&pf)[PB]) {
+    if (LAB != 6) {
+#pragma unroll
+      for (int jp = 0; jp < PB; ++jp)
+        pf[jp] = i32x4{(int)(pf[jp].x ^ xorw), (int)(pf[jp].y ^ xorw), (int)(pf[jp].z ^ xorw), (int)(pf[jp].w ^ xorw)};
+    }
+#pragma unroll
+    for (int jc = 0; jc < CB; ++jc)
+#pragma unroll
+      for (int jp = 0; jp < PB; ++jp) {
+        if (LAB == 4) asm volatile("" ::"v"(wf[jc]), "v"(pf[jp]));
+        else acc[jc][jp] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[jc], pf[jp], acc[jc][jp], 0, 0, 0);
+      }
+  };
+  constexpr int nbw = (LAB == 2 ? 0 : NBW), nhp = (LAB == 3 ? 0 : 1);
+
+  // prologue: chunk 0's tile and the first three slabs; the first wait leaves slabs 1 and 2 in flight
   static_for<HPW>([&](auto i) { issue_halo(i, 0); });
   issue_w(std::integral_constant<int, 0>{}, w_tap);
   issue_w(std::integral_constant<int, 1>{}, w_tap);
+  issue_w(std::integral_constant<int, 2>{}, w_tap);
+  if (STAMP && wgt) wgt[1] = __builtin_readcyclecounter();
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * nbw) : "memory");
+  if (tid < BN) {
+    // the per-channel constants have landed: (s_w, SUM qw) -> (s_in s_w, (shift - zp) SUM qw) in place, once per channel
+    float* pf = reinterpret_cast<float*>(par) + tid;
+    int* pi = reinterpret_cast<int*>(par) + BN + tid;
+    *pf = sin_early * *pf;
+    *pi = (shift - zpi) * *pi;
+  }
+  read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, halo, wfA, pfA);
 
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
     const int8_t* const hb = halo + (c & 1) * HALO;
+    const int8_t* const hb_next = halo + ((c + 1) & 1) * HALO;
     static_for<9>([&](auto t_c) {
       constexpr int t = decltype(t_c)::value;
       constexpr int U = t % NBUF;
-      // this step's slab (and, at t = 0, this chunk's tile) must have landed; what the previous step issued stays in flight:
-      // its slab (unless this is the very last step) and, for 1 <= t <= HPW with another chunk to come, one halo piece
-      constexpr bool HPREV = t >= 1 && t <= HPW;
-      auto wait = [&](auto nb_c) {
-        constexpr int nb = decltype(nb_c)::value;
-        if (t == 8 && !more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (HPREV && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nb + 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nb) : "memory");
-      };
-      if (BPW == 8 || wave < BPW) wait(std::integral_constant<int, 1>{});
-      else wait(std::integral_constant<int, 0>{});
-      __builtin_amdgcn_s_barrier();
-      if (t == 0 && c == 0 && tid < BN) {
-        // the per-channel constants have landed: (s_w, SUM qw) -> (s_in s_w, (shift - zp) SUM qw) in place, once per channel
-        float* pf = reinterpret_cast<float*>(par) + tid;
-        int* pi = reinterpret_cast<int*>(par) + BN + tid;
-        *pf = sin_early * *pf;
-        *pi = (shift - zpi) * *pi;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      // the slab two steps ahead goes into the slot step - 1 released; the next chunk's tile into the other halo buffer
-      if (t < 7 || more) issue_w(std::integral_constant<int, (U + 2) % NBUF>{}, t == 6 ? w_chunk : w_tap);
-      if constexpr (t < HPW) {
-        if (more) issue_halo(t_c, (c + 1) & 1);
-      }
-      constexpr int r = t / 3, s = t % 3;
-      const int p0 = pbase + (r == 0 ? 0 : (r == 1 ? tap_r1 : tap_r2)) + s;
-      const int8_t* const sb = ring + U * SLAB;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        i32x4 wf[2], pf[PB];
-#pragma unroll
-        for (int jc = 0; jc < 2; ++jc) wf[jc] = *reinterpret_cast<const i32x4*>(sb + (woff[jc] ^ (ks << 5)));
-#pragma unroll
-        for (int jp = 0; jp < PB; ++jp) {
-          const int p = p0 + jp * 32;
-          const i32x4 v = *reinterpret_cast<const i32x4*>(hb + p * 64 + (((ks * 2 + hsel) ^ ((p >> 2) & 3)) << 4));
-          pf[jp] = i32x4{(int)(v.x ^ xorw), (int)(v.y ^ xorw), (int)(v.z ^ xorw), (int)(v.w ^ xorw)};
+      stamp(0);
+      // phase 0
+      read_frags(std::integral_constant<int, U>{}, t_c, std::integral_constant<int, 1>{}, hb, wfB, pfB);
+      multiply(wfA, pfA);
+      stamp(1);
+      // phase 1
+      if (t < 8 || more) {
+        // slab s + 1 (requested three steps ago) must have landed; younger and allowed to stay in flight: slab s + 2 (unless the
+        // loop ends before it) and the halo piece step s - 1 requested behind it (steps 1 .. HPW of a chunk with a successor;
+        // never at t = 8: the next step reads the new tile, so everything but the youngest slab must be there).
+        // This wave's reads of slab s are complete (lgkmcnt) before the barrier lets anyone overwrite it.
+        constexpr bool HPREV = t >= 1 && t <= HPW && t <= 7;
+        if (t >= 7 && !more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (HPREV && more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(nbw + nhp) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(nbw) : "memory");
+        stamp(2);
+        read_frags(std::integral_constant<int, (U + 1) % NBUF>{}, std::integral_constant<int, (t + 1) % 9>{}, std::integral_constant<int, 0>{},
+                   t == 8 ? hb_next : hb, wfA, pfA);
+        // requests: a piece of the next chunk's tile into the other halo buffer, then slab s + 3 into the slot of slab s
+        if constexpr (t < HPW) {
+          if (more) issue_halo(t_c, (c + 1) & 1);
         }
-#pragma unroll
-        for (int jc = 0; jc < 2; ++jc)
-#pragma unroll
-          for (int jp = 0; jp < PB; ++jp) acc[jc][jp] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[jc], pf[jp], acc[jc][jp], 0, 0, 0);
+        if (t < 6 || more) issue_w(std::integral_constant<int, U>{}, t == 5 ? w_chunk : w_tap);
+        stamp(3);
+      }
+      multiply(wfB, pfB);
+      if (STAMP) {
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[CB - 1][PB - 1][15]));
+        stamp(4);
+        ++stepno;
       }
     });
   }
+  if (STAMP && wgt) wgt[2] = __builtin_readcyclecounter();
 
-  // ---- epilogue: lane (p = l31, h = hsel), register i of block (jc, jp) = channel n0 + wc * 64 + jc * 32 + 16 h + i of row
+  // ---- epilogue: lane (p = l31, h = hsel), register i of block (jc, jp) = channel n0 + wc * CW + jc * 32 + 16 h + i of row
   // q0 + wp * PW + jp * 32 + p.  Dequantise, quantise for the consumer, stage the code tile, store whole rows. ----
   __builtin_amdgcn_s_barrier();                   // every wave is done with the operand buffers (the code tile is staged there)
   const EpiQuant eq(ep, ep.relu != 0);            // code(relu(v)) = max(code(v), code(0))
   int8_t* const stg = lds;
+  auto row_addr = [&](int rr, bool& ok) -> uint8_t* {   // tile row -> the pixel's K code bytes (ok = it is a pixel of the batch)
+    const uint32_t q = q0 + (uint32_t)rr;
+    const uint32_t n = fdiv(q, g.fsdiv);
+    const uint32_t rem = q - n * (uint32_t)g.FS;
+    const uint32_t yy = fdiv(rem, g.wpdiv);
+    const uint32_t xx = rem - yy * (uint32_t)g.Wp;
+    ok = q < g.MQ && yy < (uint32_t)g.H && xx < (uint32_t)g.W;
+    return ep.codes + ((int64_t)((n * (uint32_t)g.H + yy) * (uint32_t)g.W + xx)) * g.K + n0;
+  };
 #pragma unroll
-  for (int jc = 0; jc < 2; ++jc) {
-    const int cb = wc * 64 + jc * 32 + hsel * 16;
+  for (int jp = 0; jp < PB; ++jp) {
+    bool ok8 = false;
+    uint8_t* dst8 = nullptr;
+    if (LAB == 8) dst8 = row_addr(wp * PW + jp * 32 + l31, ok8);
 #pragma unroll
-    for (int jp = 0; jp < PB; ++jp) {
+    for (int jc = 0; jc < CB; ++jc) {
+      const int cb = wc * CW + jc * 32 + hsel * 16;
       f32x4 y[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -238,26 +309,48 @@ __global__ __launch_bounds__(512, (HPW <= 3 && TM == 256 ? 4 : 2)) void conv3x3_
       }
       uint32_t wq[4];
       bool uq[4];
-      eq.code4n(y, wq, uq);
-      *reinterpret_cast<i32x4*>(stg + (wp * PW + jp * 32 + l31) * SROW + cb) = i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
+      if (LAB == 7) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wq[q] = __builtin_bit_cast(uint32_t, y[q].x + y[q].y + y[q].z + y[q].w);
+      } else eq.code4n(y, wq, uq);
+      const i32x4 c16 = i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
+      if (LAB == 8) {
+        if (ok8) __builtin_nontemporal_store(c16, reinterpret_cast<i32x4*>(dst8 + cb));
+      } else *reinterpret_cast<i32x4*>(stg + (wp * PW + jp * 32 + l31) * SROW + cb) = c16;
     }
   }
-  __syncthreads();                                // a row's BN bytes come from WC waves
-  constexpr int LPR = BN / 16;                    // lanes per row
-  constexpr int RPP = 512 / LPR;                  // rows per pass
-  const int srow = tid / LPR, sseg = tid % LPR;
+  if (LAB != 8) {
+    constexpr int LPR = BN / 16;                    // lanes per row
+    if constexpr (WC == 1) {                        // a wave's rows are its own: no block barrier, just the LDS counter
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int RPP = 64 / LPR;
+      const int srow = lane / LPR, sseg = lane % LPR;
 #pragma unroll
-  for (int it = 0; it < TM / RPP; ++it) {
-    const int rr = it * RPP + srow;
-    const uint32_t q = q0 + (uint32_t)rr;
-    const uint32_t n = fdiv(q, g.fsdiv);
-    const uint32_t rem = q - n * (uint32_t)g.FS;
-    const uint32_t yy = fdiv(rem, g.wpdiv);
-    const uint32_t xx = rem - yy * (uint32_t)g.Wp;
-    const i32x4 c16 = *reinterpret_cast<const i32x4*>(stg + rr * SROW + sseg * 16);
-    if (q < g.MQ && yy < (uint32_t)g.H && xx < (uint32_t)g.W)
-      __builtin_nontemporal_store(c16, reinterpret_cast<i32x4*>(ep.codes + ((int64_t)((n * (uint32_t)g.H + yy) * (uint32_t)g.W + xx)) * g.K + n0 +
-                                                                sseg * 16));
+      for (int it = 0; it < PW / RPP; ++it) {
+        const int rr = wp * PW + it * RPP + srow;
+        bool ok;
+        uint8_t* const dst = row_addr(rr, ok);
+        const i32x4 c16 = *reinterpret_cast<const i32x4*>(stg + rr * SROW + sseg * 16);
+        if (ok) __builtin_nontemporal_store(c16, reinterpret_cast<i32x4*>(dst + sseg * 16));
+      }
+    } else {
+      __syncthreads();                              // a row's BN bytes come from WC waves
+      constexpr int RPP = NT / LPR;                 // rows per pass
+      const int srow = tid / LPR, sseg = tid % LPR;
+#pragma unroll
+      for (int it = 0; it < TM / RPP; ++it) {
+        const int rr = it * RPP + srow;
+        bool ok;
+        uint8_t* const dst = row_addr(rr, ok);
+        const i32x4 c16 = *reinterpret_cast<const i32x4*>(stg + rr * SROW + sseg * 16);
+        if (ok) __builtin_nontemporal_store(c16, reinterpret_cast<i32x4*>(dst + sseg * 16));
+      }
+    }
+  }
+  if (STAMP && wgt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wgt[3] = __builtin_readcyclecounter();
+    wgt[5] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -272,7 +365,7 @@ bool conv3x3_halo_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
 
 int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, const int32_t* wsum, const float* in_scale,
                         const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
-                        int shift, const ConvEpi& ep, hipStream_t st) {
+                        int shift, const ConvEpi& ep, hipStream_t st, int lab, void* lab_trace) {
   constexpr int TM = 256;
   HaloGeom g;
   g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C = (int)C; g.K = (int)K;
@@ -286,9 +379,34 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
   const int64_t nblk_m = ((int64_t)g.MQ + TM - 1) / TM;
   const int64_t nwg = nblk_m * g.nblk_n;
   if (nwg >= (1ll << 31)) return DLMCQ_ERANGE;
-#define DLMCQ_HALO_ARGS dim3((uint32_t)nwg), dim3(512), 0, st, x, w, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep
-  if (g.hp <= 24) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 3>), DLMCQ_HALO_ARGS);
-  else if (g.hp <= 32) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 4>), DLMCQ_HALO_ARGS);
+  unsigned long long* const trace = static_cast<unsigned long long*>(lab_trace);
+#define DLMCQ_HALO_ARGS(NW) dim3((uint32_t)nwg), dim3(NW * 64), 0, st, x, w, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, trace
+#ifdef DLMCQ_LAB
+  if (lab) {     // lab: variant = lab % 100 on the 4-wave tiling, + 100 for the 8-wave tiling (0 / 100 = the product code of each)
+    const int v = lab % 100;
+    if (g.hp > 24 || (v == 1 && !trace)) return DLMCQ_EINVAL;
+    if (lab >= 100) {
+      switch (v) {
+#define DLMCQ_HALO_LAB(V) case V: hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 8, 2, 3, V>), DLMCQ_HALO_ARGS(8)); break
+        DLMCQ_HALO_LAB(0); DLMCQ_HALO_LAB(1); DLMCQ_HALO_LAB(2); DLMCQ_HALO_LAB(3); DLMCQ_HALO_LAB(4); DLMCQ_HALO_LAB(6); DLMCQ_HALO_LAB(7); DLMCQ_HALO_LAB(8);
+#undef DLMCQ_HALO_LAB
+        default: return DLMCQ_EINVAL;
+      }
+    } else {
+      switch (v) {
+#define DLMCQ_HALO_LAB(V) case V: hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 4, 1, 6, V>), DLMCQ_HALO_ARGS(4)); break
+        DLMCQ_HALO_LAB(1); DLMCQ_HALO_LAB(2); DLMCQ_HALO_LAB(3); DLMCQ_HALO_LAB(4); DLMCQ_HALO_LAB(6); DLMCQ_HALO_LAB(7); DLMCQ_HALO_LAB(8);
+#undef DLMCQ_HALO_LAB
+        default: return DLMCQ_EINVAL;
+      }
+    }
+    return launch_status();
+  }
+#else
+  if (lab) return DLMCQ_EINVAL;
+#endif
+  if (g.hp <= 24) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 4, 1, 6>), DLMCQ_HALO_ARGS(4));
+  else if (g.hp <= 32) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 4, 1, 8>), DLMCQ_HALO_ARGS(4));
   else return DLMCQ_EINVAL;
 #undef DLMCQ_HALO_ARGS
   return launch_status();

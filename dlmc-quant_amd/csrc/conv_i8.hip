@@ -822,6 +822,14 @@ extern "C" int dlmcq_x_conv2d_i8_tuned(const void* x, const int8_t* w, float* ou
     return dlmcq_conv_pp_launch(reinterpret_cast<const int8_t*>(x), w, out, bias, wsum, in_scale, in_zero_point, w_scale, g,
                                 x_is_unsigned ? 128 : 0, ep, nullptr, bn, pp_nbuf, pp_wps, reinterpret_cast<hipStream_t>(stream));
   }
+  if (pp_wps <= -100) {    // the halo kernel's what-bounds-the-step variants (LAB = -pp_wps - 100); 1 = stamps into `residual`
+    if (!conv3x3_halo_applies(N, H, W, C, K, R, S, stride, pad, dilation, ConvEpi{nullptr, nullptr, ep.codes}, nullptr, false)) return DLMCQ_EINVAL;
+    ConvEpi e2 = ep;
+    e2.residual = nullptr;
+    return conv3x3_halo_launch(reinterpret_cast<const int8_t*>(x), w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K,
+                               x_is_unsigned ? 128 : 0, e2, reinterpret_cast<hipStream_t>(stream), -pp_wps - 100,
+                               const_cast<float*>(residual));
+  }
   if (pp_wps < 0) {   // what-bounds-the-step variants of the 128-wide direct-A kernel (LAB = -pp_wps)
     const int64_t P = (H + 2 * pad - dilation * (R - 1) - 1) / stride + 1, Q = (W + 2 * pad - dilation * (S - 1) - 1) / stride + 1;
     if (C % CV_BK || K % 128 || P < 1 || Q < 1 || N * P * Q >= (1ll << 31)) return DLMCQ_EINVAL;

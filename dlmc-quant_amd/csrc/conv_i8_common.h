@@ -66,7 +66,7 @@ bool conv3x3_halo_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
                           int32_t dilation, const ConvEpi& ep, const float* out, bool dual);
 int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, const int32_t* wsum, const float* in_scale,
                         const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
-                        int shift, const ConvEpi& ep, hipStream_t st);
+                        int shift, const ConvEpi& ep, hipStream_t st, int lab = 0, void* lab_trace = nullptr);
 
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
