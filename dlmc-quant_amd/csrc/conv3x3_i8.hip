@@ -43,8 +43,13 @@ struct HaloGeom {
 // LAB (lab library only; results are garbage except for 0 and 1, only the time means something): 1 = clock stamps into `trace`;
 // 2 = no weight DMA, 3 = no halo DMA, 4 = no MFMAs, 6 = no xor of the pixel fragments, 7 = no quantising epilogue,
 // 8 = codes stored straight from the accumulator layout (32-byte pieces, no staging through LDS)
-template <int BN, int TM, int NW, int WC, int HPW, int LAB = 0>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? (HPW <= 3 ? 4 : 2) : (HPW <= 6 ? 2 : 1))) void conv3x3_halo_i8_kernel(
+// NHB = halo buffers: 2, or 1 for layers with ONE 64-channel chunk (C = 64: nothing to prefetch; the LDS saved buys a third
+// workgroup per CU, whose K loop covers the others' quantising epilogues - at 9 K steps per tile those are most of a tile's life).
+// WPE = waves per SIMD the registers are budgeted for.  XS = the activation codes are uint8 and every pixel fragment is re-centred
+// (^ 0x80) on its way to the matrix cores; producers that emit `code - 128` (DLMCQ_EMIT_SHIFT128) spare this kernel 16 of its ~45
+// vector instructions per K step.
+template <int BN, int TM, int NW, int WC, int HPW, int NHB, int WPE, bool XS, int LAB = 0>
+__global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, const float* __restrict__ bias, const int32_t* __restrict__ wsum,
     const float* __restrict__ s_in, const float* __restrict__ zp_in, const float* __restrict__ s_w, HaloGeom g, int shift, ConvEpi ep,
     unsigned long long* __restrict__ trace) {
@@ -63,10 +68,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? (HPW <= 3 ? 4 : 2) : (HPW <= 6 
   constexpr int RING = NBUF * SLAB;
   constexpr int SROW = BN + 16;             // staged code row (conflict-free 16-byte accesses)
   constexpr int STAGE = TM * SROW;
-  constexpr int OPER = RING + 2 * HALO;
+  constexpr int OPER = RING + NHB * HALO;
   constexpr int LDS_BYTES = OPER < STAGE ? STAGE : OPER;
   constexpr int PAR_BYTES = 3 * BN * 4;
-  static_assert(PB >= 1 && CB >= 1 && NBW >= 1 && NBW * NW * 1024 == SLAB && HPW <= 8 && BN % 64 == 0, "tile shape");
+  static_assert(PB >= 1 && CB >= 1 && NBW >= 1 && NBW * NW * 1024 == SLAB && HPW <= 8 && BN % 64 == 0 && (NHB == 1 || NHB == 2), "tile shape");
   __shared__ __attribute__((aligned(1024))) int8_t lds[LDS_BYTES + PAR_BYTES];
   int8_t* const ring = lds;
   int8_t* const halo = lds + RING;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? (HPW <= 3 ? 4 : 2) : (HPW <= 6 
   const float zpf = zp_in ? zp_in[0] : 0.0f;
   const int zpi = (int)__builtin_rintf(zpf);
   const float sin_early = s_in[0];
-  const uint32_t xorw = shift ? 0x80808080u : 0u;
+  const uint32_t xorw = 0x80808080u;
   const int8_t* const padline = g_pad_table.b + ((zpi & 0xff) << 6);     // stored UNshifted: the xor happens on read
 
   // ---- halo DMA: piece i of this wave covers halo positions (i * NW + wave) * 16 .. + 15; LDS slot s of position p holds the
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? (HPW <= 3 ? 4 : 2) : (HPW <= 6 
     for (int jp = 0; jp < PB; ++jp) pf[jp] = *reinterpret_cast<const i32x4*>(hbuf + pa + jp * 2048);
   };
   auto multiply = [&](const i32x4 (&wf)[CB], i32x4 (&pf)[PB]) {
-    if (LAB != 6) {
+    if (XS && LAB != 6) {
 #pragma unroll
       for (int jp = 0; jp < PB; ++jp)
         pf[jp] = i32x4{(int)(pf[jp].x ^ xorw), (int)(pf[jp].y ^ xorw), (int)(pf[jp].z ^ xorw), (int)(pf[jp].w ^ xorw)};
@@ -234,10 +239,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? (HPW <= 3 ? 4 : 2) : (HPW <= 6 
   }
   read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, halo, wfA, pfA);
 
-  for (int c = 0; c < nchunks; ++c) {
-    const bool more = c + 1 < nchunks;
-    const int8_t* const hb = halo + (c & 1) * HALO;
-    const int8_t* const hb_next = halo + ((c + 1) & 1) * HALO;
+  for (int c = 0; c < (NHB == 1 ? 1 : nchunks); ++c) {
+    const bool more = NHB == 2 && c + 1 < nchunks;
+    const int8_t* const hb = halo + (NHB == 2 ? (c & 1) * HALO : 0);
+    const int8_t* const hb_next = halo + (NHB == 2 ? ((c + 1) & 1) * HALO : 0);
     static_for<9>([&](auto t_c) {
       constexpr int t = decltype(t_c)::value;
       constexpr int U = t % NBUF;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? (HPW <= 3 ? 4 : 2) : (HPW <= 6 
         read_frags(std::integral_constant<int, (U + 1) % NBUF>{}, std::integral_constant<int, (t + 1) % 9>{}, std::integral_constant<int, 0>{},
                    t == 8 ? hb_next : hb, wfA, pfA);
         // requests: a piece of the next chunk's tile into the other halo buffer, then slab s + 3 into the slot of slab s
-        if constexpr (t < HPW) {
+        if constexpr (t < HPW && NHB == 2) {
           if (more) issue_halo(t_c, (c + 1) & 1);
         }
         if (t < 6 || more) issue_w(std::integral_constant<int, U>{}, t == 5 ? w_chunk : w_tap);
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? (HPW <= 3 ? 4 : 2) : (HPW <= 6 
 bool conv3x3_halo_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
                           int32_t dilation, const ConvEpi& ep, const float* out, bool dual) {
   if (R != 3 || S != 3 || stride != 1 || pad != 1 || dilation != 1 || dual || out || ep.residual || ep.w_off || !ep.codes) return false;
-  if (C % 64 != 0 || K % 128 != 0 || !aligned16(ep.codes)) return false;
+  if (C % 64 != 0 || K % 64 != 0 || !aligned16(ep.codes)) return false;
   if (W + 1 > 120 || N * (H + 1) * (W + 1) + 1024 >= (1ll << 31) || N * H * W * C >= (1ll << 31)) return false;
   return true;
 }
@@ -367,12 +372,13 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
                         const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
                         int shift, const ConvEpi& ep, hipStream_t st, int lab, void* lab_trace) {
   constexpr int TM = 256;
+  const int bn = K % 128 == 0 ? 128 : 64;
   HaloGeom g;
   g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C = (int)C; g.K = (int)K;
   g.Wp = (int)W + 1;
   g.FS = (int)((H + 1) * (W + 1));
   g.MQ = (uint32_t)(N * g.FS);
-  g.nblk_n = (int)(K / 128);
+  g.nblk_n = (int)(K / bn);
   g.hp = (TM + 2 * g.Wp + 2 + 15) / 16;
   g.fsdiv = make_fastdiv((uint32_t)g.FS);
   g.wpdiv = make_fastdiv((uint32_t)g.Wp);
@@ -382,19 +388,28 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
   unsigned long long* const trace = static_cast<unsigned long long*>(lab_trace);
 #define DLMCQ_HALO_ARGS(NW) dim3((uint32_t)nwg), dim3(NW * 64), 0, st, x, w, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, trace
 #ifdef DLMCQ_LAB
-  if (lab) {     // lab: variant = lab % 100 on the 4-wave tiling, + 100 for the 8-wave tiling (0 / 100 = the product code of each)
+  if (lab) {     // lab: variant = lab % 100 on the product tiling, + 100 for the 8-wave tiling (100 = its product code)
     const int v = lab % 100;
     if (g.hp > 24 || (v == 1 && !trace)) return DLMCQ_EINVAL;
     if (lab >= 100) {
+      if (bn != 128) return DLMCQ_EINVAL;
       switch (v) {
-#define DLMCQ_HALO_LAB(V) case V: hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 8, 2, 3, V>), DLMCQ_HALO_ARGS(8)); break
-        DLMCQ_HALO_LAB(0); DLMCQ_HALO_LAB(1); DLMCQ_HALO_LAB(2); DLMCQ_HALO_LAB(3); DLMCQ_HALO_LAB(4); DLMCQ_HALO_LAB(6); DLMCQ_HALO_LAB(7); DLMCQ_HALO_LAB(8);
+#define DLMCQ_HALO_LAB(V) case V: hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 8, 2, 3, 2, 4, true, V>), DLMCQ_HALO_ARGS(8)); break
+        DLMCQ_HALO_LAB(0); DLMCQ_HALO_LAB(1); DLMCQ_HALO_LAB(4);
+#undef DLMCQ_HALO_LAB
+        default: return DLMCQ_EINVAL;
+      }
+    } else if (bn == 128) {
+      switch (v) {
+#define DLMCQ_HALO_LAB(V) case V: hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 4, 1, 6, 2, 2, true, V>), DLMCQ_HALO_ARGS(4)); break
+        DLMCQ_HALO_LAB(1); DLMCQ_HALO_LAB(2); DLMCQ_HALO_LAB(3); DLMCQ_HALO_LAB(4); DLMCQ_HALO_LAB(6); DLMCQ_HALO_LAB(7); DLMCQ_HALO_LAB(8);
 #undef DLMCQ_HALO_LAB
         default: return DLMCQ_EINVAL;
       }
     } else {
+      if (C != 64) return DLMCQ_EINVAL;
       switch (v) {
-#define DLMCQ_HALO_LAB(V) case V: hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 4, 1, 6, V>), DLMCQ_HALO_ARGS(4)); break
+#define DLMCQ_HALO_LAB(V) case V: hipLaunchKernelGGL((conv3x3_halo_i8_kernel<64, TM, 4, 1, 6, 1, 4, true, V>), DLMCQ_HALO_ARGS(4)); break
         DLMCQ_HALO_LAB(1); DLMCQ_HALO_LAB(2); DLMCQ_HALO_LAB(3); DLMCQ_HALO_LAB(4); DLMCQ_HALO_LAB(6); DLMCQ_HALO_LAB(7); DLMCQ_HALO_LAB(8);
 #undef DLMCQ_HALO_LAB
         default: return DLMCQ_EINVAL;
@@ -405,9 +420,24 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
 #else
   if (lab) return DLMCQ_EINVAL;
 #endif
-  if (g.hp <= 24) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 4, 1, 6>), DLMCQ_HALO_ARGS(4));
-  else if (g.hp <= 32) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 4, 1, 8>), DLMCQ_HALO_ARGS(4));
-  else return DLMCQ_EINVAL;
+#define DLMCQ_HALO_GO(NW, ...)                                                                            \
+  do {                                                                                                   \
+    if (shift) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<__VA_ARGS__, true>), DLMCQ_HALO_ARGS(NW));    \
+    else hipLaunchKernelGGL((conv3x3_halo_i8_kernel<__VA_ARGS__, false>), DLMCQ_HALO_ARGS(NW));         \
+  } while (0)
+  if (g.hp > 32) return DLMCQ_EINVAL;
+  const bool wide = g.hp > 24;        // images wider than 57 pixels: 8 halo pieces per wave, one workgroup per CU
+  if (bn == 128) {
+    if (!wide) DLMCQ_HALO_GO(4, 128, TM, 4, 1, 6, 2, 2);
+    else DLMCQ_HALO_GO(4, 128, TM, 4, 1, 8, 2, 1);
+  } else if (C == 64) {
+    if (!wide) DLMCQ_HALO_GO(4, 64, TM, 4, 1, 6, 1, 4);
+    else DLMCQ_HALO_GO(4, 64, TM, 4, 1, 8, 1, 3);
+  } else {
+    if (!wide) DLMCQ_HALO_GO(4, 64, TM, 4, 1, 6, 2, 2);
+    else DLMCQ_HALO_GO(4, 64, TM, 4, 1, 8, 2, 2);
+  }
+#undef DLMCQ_HALO_GO
 #undef DLMCQ_HALO_ARGS
   return launch_status();
 }

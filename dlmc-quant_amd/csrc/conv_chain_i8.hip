@@ -409,8 +409,9 @@ static int chain_launch(ChainArgs& a, int64_t M, int64_t C, int64_t K, int64_t C
                         int32_t relu2, void* codes2, const float* q2_scale, const float* q2_zero_point, int32_t q2_lo, int32_t q2_hi,
                         int32_t q2_form, float q2_ste_g, int32_t rows_per_tile, dlmcq_stream_t stream) {
   if (q_lo != 0 || q_hi != 255) return DLMCQ_EINVAL;   // GEMM 2 reads the codes as uint8 (shift 128)
+  ConvEpi ep1{}, ep2{};
   if (q2_lo > q2_hi || q2_lo < -128 || q2_hi > 255 || q2_hi - q2_lo > 255 || q_form < DLMCQ_FORM_EMULATE ||
-      q_form > DLMCQ_FORM_SYMMETRIC || q2_form < DLMCQ_FORM_EMULATE || q2_form > DLMCQ_FORM_SYMMETRIC)
+      q_form > DLMCQ_FORM_SYMMETRIC || !epi_set_form(ep2, q2_form, q2_lo, q2_hi))
     return DLMCQ_EINVAL;
   if (M * K * 4 > (int64_t)CH_BIG) return DLMCQ_ERANGE;   // 32-bit buffer offsets
   a.M = (int)M; a.KD = (int)K;
@@ -420,11 +421,10 @@ static int chain_launch(ChainArgs& a, int64_t M, int64_t C, int64_t K, int64_t C
 #endif
   a.rows_per_tile = rows_per_tile > 0 ? rows_per_tile : 64;   // (tile heights that fill the last round of workgroups exactly - 56, 49 - measured slower)
   if (a.rows_per_tile > 64) return DLMCQ_EINVAL;
-  ConvEpi ep1{}, ep2{};
   ep1.relu = relu != 0; ep1.q_scale = q_scale; ep1.q_zp = q_zero_point; ep1.q_lo = (float)q_lo; ep1.q_hi = (float)q_hi;
   ep1.q_g = q_ste_g; ep1.q_form = q_form; ep1.codes = static_cast<uint8_t*>(codes);
   ep2.relu = relu2 != 0; ep2.q_scale = q2_scale; ep2.q_zp = q2_zero_point; ep2.q_lo = (float)q2_lo; ep2.q_hi = (float)q2_hi;
-  ep2.q_g = q2_ste_g; ep2.q_form = q2_form; ep2.codes = static_cast<uint8_t*>(codes2);
+  ep2.q_g = q2_ste_g; ep2.codes = static_cast<uint8_t*>(codes2);
   const int64_t tiles = (M + a.rows_per_tile - 1) / a.rows_per_tile;
   if (tiles >= (1ll << 31)) return DLMCQ_ERANGE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -23,7 +23,16 @@ struct ConvEpi {
   float q_lo, q_hi, q_g;
   int q_form;
   int relu;
+  uint32_t q_xor;          // 0x80808080 when the codes are stored as int8 `code - 128` (DLMCQ_EMIT_SHIFT128), else 0
 };
+
+// `q_form` argument of an entry point -> (form, shifted-emission flag); false = invalid
+static inline bool epi_set_form(ConvEpi& ep, int32_t q_form, int32_t q_lo, int32_t q_hi) {
+  const bool shifted = (q_form & DLMCQ_EMIT_SHIFT128) != 0;
+  ep.q_form = q_form & ~DLMCQ_EMIT_SHIFT128;
+  ep.q_xor = shifted ? 0x80808080u : 0u;
+  return ep.q_form >= DLMCQ_FORM_EMULATE && ep.q_form <= DLMCQ_FORM_SYMMETRIC && (!shifted || (q_lo >= 0 && q_hi <= 255));
+}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -60,12 +69,13 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
   float dv, rdv, of, zadd, lo, hi;
   float lo_fast;    // lower clamp of the fast path: `lo`, or max(lo, code of 0) when the ReLU is folded into the quantiser
   int form;
+  uint32_t xemit;   // DLMCQ_EMIT_SHIFT128: every emitted byte ^ 0x80
   bool sgn, fold;
   // fold_relu: the caller quantises relu(v) but passes v: every form is monotone, so code(relu(v)) = max(code(v), code(0))
   // for a finite v - one clamp bound instead of a compare + select per element (NaN takes the exact path, which rectifies)
   __device__ __forceinline__ EpiQuant(const ConvEpi& ep, bool fold_relu = false)
       : tie_thr(0.5f - 0x1p-13f), dv(1.0f), rdv(1.0f), of(0.0f), zadd(0.0f), lo(ep.q_lo), hi(ep.q_hi), lo_fast(ep.q_lo), form(ep.q_form),
-        sgn(ep.q_lo < 0.0f), fold(fold_relu) {
+        xemit(ep.q_xor), sgn(ep.q_lo < 0.0f), fold(fold_relu) {
     if (!ep.codes) return;
     const float s = ep.q_scale[0];
     const float z = ep.q_zp ? ep.q_zp[0] : 0.0f;
@@ -96,7 +106,7 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
     if (form == DLMCQ_FORM_ZEROPOINT) return clamp_nan(ste_round(v / dv) + zadd, lo, hi);
     return clamp_nan(ste_round(v / dv), lo, hi);
   }
-  __device__ __forceinline__ uint32_t exact(float v) const { return (uint32_t)(code_of(exact_q(v)) & 0xff); }
+  __device__ __forceinline__ uint32_t exact(float v) const { return (uint32_t)(code_of(exact_q(v)) & 0xff) ^ (xemit & 0xffu); }
   // The rare path of code4: `wfast` holds the fast path's bytes, of which at least one failed its tie test in this lane.
   // Only the failing ELEMENTS are redone (the test is repeated per element; an element that passes keeps its fast byte,
   // which the argument below vouches for element by element), and the exact division exists once, in a loop over the set
@@ -166,7 +176,7 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
     uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(q0, 0, 0u);
     w = __builtin_amdgcn_cvt_pk_u8_f32(q1, 1, w);
     w = __builtin_amdgcn_cvt_pk_u8_f32(q2, 2, w);
-    return __builtin_amdgcn_cvt_pk_u8_f32(q3, 3, w);
+    return __builtin_amdgcn_cvt_pk_u8_f32(q3, 3, w) ^ xemit;
   }
   __device__ __forceinline__ uint32_t code4(const f32x4& v) const {
     bool unsure;

@@ -687,7 +687,7 @@ static ConvEpi make_epi(const float* residual, int32_t relu, void* codes, const 
   ep.q_lo = (float)q_lo;
   ep.q_hi = (float)q_hi;
   ep.q_g = q_ste_g;
-  ep.q_form = q_form;
+  if (!epi_set_form(ep, q_form, q_lo, q_hi)) ep.q_form = -1;     // (conv_launch refuses it)
   return ep;
 }
 

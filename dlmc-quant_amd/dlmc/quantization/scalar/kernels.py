@@ -42,6 +42,11 @@ class _Profile:
 PROFILE = _Profile()
 
 
+def _no_shift(emit, what):
+    if emit is not None and emit.shift128:
+        raise ValueError(f"{what}: this entry point does not emit shifted codes (EmitCodes.shift128)")
+
+
 def _f32c(t, like):
     """A contiguous fp32 tensor on `like`'s device (scale / offset operands)."""
     if t is None:
@@ -364,12 +369,22 @@ def quantize_weight_krsc(w, scale, lo, hi):
 class EmitCodes:
     """The consumer's activation quantiser, for a producer that emits its codes directly (conv2d_i8 `emit=`)."""
 
-    def __init__(self, scale, zero_point, lo, hi, form, g=0.0):
+    def __init__(self, scale, zero_point, lo, hi, form, g=0.0, shift128=False):
         self.scale, self.zero_point, self.lo, self.hi, self.form, self.g = scale, zero_point, int(lo), int(hi), int(form), float(g)
+        # shift128 (unsigned byte ranges only): the codes are stored as int8 `code - 128` (DLMCQ_EMIT_SHIFT128) - what the matrix
+        # cores multiply anyway; the consumer passes them as signed codes with the zero point `zp - 128` (same integers, same results)
+        self.shift128 = bool(shift128)
+        if self.shift128 and not (0 <= self.lo and self.hi <= 255):
+            raise ValueError("EmitCodes: shift128 needs an unsigned byte range")
 
     @property
     def dtype(self):
-        return torch.uint8 if self.lo >= 0 else torch.int8
+        return torch.uint8 if self.lo >= 0 and not self.shift128 else torch.int8
+
+    @property
+    def form_arg(self):
+        """The `q_form` argument of the entry points that accept the shifted emission."""
+        return self.form | (N.EMIT_SHIFT128 if self.shift128 else 0)
 
 
 def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1,
@@ -432,7 +447,7 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
             out_codes = alloc(emit.dtype)
             q_scale = _f32c(emit.scale.detach(), ref).reshape(-1)
             q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, ref).reshape(-1)
-            lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
+            lo, hi, form, g = emit.lo, emit.hi, emit.form_arg, emit.g
         nbytes = codes.numel() + wq.numel() + out_elems * (4 * (out is not None) + 4 * (residual is not None) + (emit is not None))
         if w_offset is not None:
             PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_asym(
@@ -452,6 +467,7 @@ def conv2d_dw_i8(codes, wq, bias, in_scale, in_zp, w_scale, w_offset=None, strid
     """Depthwise convolution on activation codes (dlmcq_conv2d_dw_i8_nhwc).  codes: (N, C, H, W) uint8/int8 channels_last,
     C % 4 == 0; wq: int8 [R, S, C] (tap-major); per-channel w_scale / w_offset / bias [C].  Returns fp32 (N, C, P, Q)
     channels_last, or `(out, codes)` with `emit`."""
+    _no_shift(emit, "conv2d_dw_i8")
     N.require_gpu(codes, wq)
     n, c, h, w_ = codes.shape
     if not codes.is_contiguous(memory_format=torch.channels_last):
@@ -525,7 +541,7 @@ def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True):
         out_codes = alloc(emit.dtype)
         q_scale = _f32c(emit.scale.detach(), ca).reshape(-1)
         q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, ca).reshape(-1)
-        lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
+        lo, hi, form, g = emit.lo, emit.hi, emit.form_arg, emit.g
     h, w_, ch, R, S, st, pd, dl, uns = ga
     h2, w2, ch2, R2, S2, st2, pd2, dl2, uns2 = gb
     oe = n * K_ * P * Q
@@ -554,6 +570,7 @@ def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_co
     convolution (+ ReLU, its consumer's quantiser `emit2`) in one kernel (dlmcq_conv2d_i8_nhwc_chain).  `a`: dict with
     codes, wq, wsum, bias, in_scale, in_zp, w_scale of the first layer; `b`: wq, wsum, bias, w_scale of the second (its
     input quantiser is `emit`).  Returns (out or None, codes or None, codes2)."""
+    _no_shift(emit, "conv2d_i8_chain")
     c = a["codes"]
     N.require_gpu(c, a["wq"], b["wq"], residual)
     if not c.is_contiguous(memory_format=torch.channels_last):
@@ -590,7 +607,7 @@ def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_co
         N.ptr(c), N.ptr(a["wq"]), N.ptr(out), N.ptr(b1), N.ptr(a["wsum"]), N.ptr(si), N.ptr(zp), N.ptr(ws1), m, ch, K_,
         int(c.dtype == torch.uint8), N.ptr(residual), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi,
         emit.form, emit.g, N.ptr(b["wq"]), N.ptr(b2), N.ptr(b["wsum"]), N.ptr(ws2), K2, int(bool(relu2)), N.ptr(codes2),
-        N.ptr(qs2), N.ptr(qz2), emit2.lo, emit2.hi, emit2.form, emit2.g, int(rows_per_tile), N.stream_ptr())))
+        N.ptr(qs2), N.ptr(qz2), emit2.lo, emit2.hi, emit2.form_arg, emit2.g, int(rows_per_tile), N.stream_ptr())))
     return out, codes, codes2
 
 
@@ -605,6 +622,7 @@ def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_cod
     """conv1x1(a) + conv1x1(b, strided) (+ ReLU, the consumer's quantiser `emit`) and the next 1x1 convolution `c3` on the
     codes, in one kernel (dlmcq_conv2d_i8_nhwc_dual_chain).  `a`, `b`: operand dicts as for conv2d_i8_dual (`b` may carry a
     stride); `c3`: wq, wsum, bias, w_scale.  Returns (out or None, codes or None, codes3)."""
+    _no_shift(emit, "conv2d_i8_dual_chain")
     ca, cb = a["codes"], b["codes"]
     N.require_gpu(ca, cb, a["wq"], b["wq"], c3["wq"])
     if not ca.is_contiguous(memory_format=torch.channels_last):
@@ -647,7 +665,7 @@ def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_cod
         int(ca.dtype == torch.uint8), N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2,
         ch2, st2, int(cb.dtype == torch.uint8), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi, emit.form, emit.g,
         N.ptr(c3["wq"]), N.ptr(b3), N.ptr(c3["wsum"]), N.ptr(ws3), K3, int(bool(relu3)), N.ptr(codes3), N.ptr(qs3), N.ptr(qz3), emit3.lo,
-        emit3.hi, emit3.form, emit3.g, int(rows_per_tile), N.stream_ptr())))
+        emit3.hi, emit3.form_arg, emit3.g, int(rows_per_tile), N.stream_ptr())))
     return out, codes, codes3
 
 
@@ -690,6 +708,7 @@ def conv2d_i8_stem(xpad, wq, wsum, bias, in_scale, in_zp, w_scale, S, stride=1, 
     (N, K, P, Q) channels_last, or `(out, codes)` with `emit` (see conv2d_i8).  `pool=True` (K <= 64): followed by
     MaxPool2d(3, 2, 1) in the same kernel - the results are the pooled tensors.  `w_offset` ([K] fp32, with the image's real
     channel count `channels`): asymmetric per-channel weights (dlmcq_conv2d_i8_stem_asym; not with `pool`)."""
+    _no_shift(emit, "conv2d_i8_stem")
     N.require_gpu(xpad, wq)
     n, hp, wp, _ = xpad.shape
     K_, R = wq.shape[0], wq.shape[1]

@@ -166,6 +166,14 @@ class _PlanLayer(nn.Module):
         self.register_buffer("bias_pad", None if layer.bias is None or self.k_pad == k else self._padk(layer.bias.detach().float(), 0.0),
                              persistent=False)
         self._zp_fill = int(0 if self.act.zp is None else float(self.act.zp.reshape(-1)[0]))   # (read once: no host sync in forward)
+        # A producer may hand an unsigned-byte quantiser's codes over as int8 `code - 128` (EmitCodes.shift128: what the matrix
+        # cores multiply anyway, so the consumer's kernel need not re-centre every operand byte it reads); this node then runs
+        # with the zero point `zp - 128` - the same integers.  `emit_shift`: this node emits ITS consumers' codes that way.
+        self.emit_shift = False
+        zs = None
+        if self.act.lo >= 0:
+            zs = (torch.zeros(1, device=w_scale.device) if self.act.zp is None else self.act.zp.detach().float().reshape(-1)[:1]) - 128.0
+        self.register_buffer("zp_shift", zs, persistent=False)
         self._deq = {}     # QBase dequantises with s^ = grad_scale(s, g(numel)): one tiny tensor per input size
 
     def _padk(self, v, fill):
@@ -192,7 +200,13 @@ class _PlanLayer(nn.Module):
         if self.pool is not None:
             kk, ss, pp = self.pool
             p, q = (p + 2 * pp - kk) // ss + 1, (q + 2 * pp - kk) // ss + 1
-        return self.emit.emit(n * k * p * q)
+        e = self.emit.emit(n * k * p * q)
+        e.shift128 = self.emit_shift
+        return e
+
+    def _zp(self, codes):
+        """The zero point that goes with `codes`: int8 codes of an unsigned quantiser are shifted codes (see __init__)."""
+        return self.zp_shift if (codes.dtype == torch.int8 and self.act.lo >= 0) else self.act.zp
 
     def _finish(self, out, codes):
         if self.pool is not None:
@@ -283,7 +297,7 @@ class Int8Layer(_PlanLayer):
         """This layer as one addend of conv2d_i8_dual."""
         codes = self._codes(x)
         return dict(codes=codes, wq=self.wq, wsum=self.wsum, bias=self._bias(), in_scale=self._in_scale(self._real_numel(codes)),
-                    in_zp=self.act.zp, w_scale=self.w_scale, **self._conv_kw())
+                    in_zp=self._zp(codes), w_scale=self.w_scale, **self._conv_kw())
 
     def forward(self, x, residual=None):
         lay, act = self.layer, self.act
@@ -301,11 +315,11 @@ class Int8Layer(_PlanLayer):
         if self.w_off is not None:
             kw["w_offset"] = self.w_off
         if self.relu or residual is not None or emit is not None or self.w_off is not None:
-            res = K.conv2d_i8(codes, self.wq, self.wsum, self._bias(), self._in_scale(numel), act.zp, self.w_scale,
+            res = K.conv2d_i8(codes, self.wq, self.wsum, self._bias(), self._in_scale(numel), self._zp(codes), self.w_scale,
                               residual=residual, relu=self.relu, emit=emit, want_out=self.want_out, **kw)
             out, out_codes = res if emit is not None else (res, None)
         else:
-            out, out_codes = K.conv2d_i8(codes, self.wq, self.wsum, self._bias(), self._in_scale(numel), act.zp, self.w_scale, **kw), None
+            out, out_codes = K.conv2d_i8(codes, self.wq, self.wsum, self._bias(), self._in_scale(numel), self._zp(codes), self.w_scale, **kw), None
         if lead is not None:
             out = None if out is None else out.reshape(*lead, out.shape[-1])
             out_codes = None if out_codes is None else out_codes.reshape(*lead, out_codes.shape[-1])
@@ -380,7 +394,7 @@ class ChainInt8Layer(nn.Module):
             if not K.chain_supported(c, a.k, b.k, n * h * w):
                 out, mid = a(x, y)
                 return out, (mid if self.want_codes else None), b(mid)[1]
-            oa = dict(codes=codes, wq=a.wq, wsum=a.wsum, bias=a._bias(), in_scale=a._in_scale(a._real_numel(codes)), in_zp=a.act.zp,
+            oa = dict(codes=codes, wq=a.wq, wsum=a.wsum, bias=a._bias(), in_scale=a._in_scale(a._real_numel(codes)), in_zp=a._zp(codes),
                       w_scale=a.w_scale)
             return K.conv2d_i8_chain(oa, nxt, y, relu2=b.relu, **kw)
         if not K.dual_chain_supported(c, sc.c, a.k, b.k, n * h * w):
@@ -438,6 +452,7 @@ def _chain_pass(gm, report):
             continue
         name = f"_int8_chain_{count}"
         count += 1
+        a.emit_shift = False        # the chain kernel's second GEMM reads those codes in place, as unsigned bytes
         gm.add_module(name, ChainInt8Layer(a, b, want_codes=len(g1.users) > 1, short=short, main=main))
         with graph.inserting_after(na):
             nc = graph.call_module(name, args=na.args)
@@ -659,6 +674,15 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True):
             gm.add_module(name, _DryNode())
         else:
             plan = cls(modules[node.target], spec, relu=relu, emit=emit, want_out=fp32_needed or emit is None, pool=pool)
+            # codes of an unsigned-byte quantiser read only by matrix-core layers (no channel padding, no pooling on the way)
+            # travel re-centred (see _PlanLayer.__init__); the consumers recognise them by dtype
+            def takes_shifted(u):
+                sp = spec_of(u) if u.op == "call_module" else None
+                m = modules.get(u.target) if u.op == "call_module" else None
+                return (sp is not None and sp[4] == "gemm" and m is not None and m.weight.dim() == 4 and m.groups == 1 and
+                        m.weight.shape[1] % 64 == 0)
+            plan.emit_shift = bool(cls is Int8Layer and emit is not None and 0 <= emit.lo and emit.hi <= 255 and pool is None and
+                                   plan.k_pad == plan.k and takers and all(takes_shifted(u) for u in takers))
             gm.add_module(name, DualInt8Layer(plan, Int8Layer(modules[residual.target], other)) if dual else plan)
         if dual:
             args = (node.args[0], residual.args[0])

@@ -65,6 +65,14 @@ typedef void* dlmcq_stream_t; /* hipStream_t */
                                   u = s*(hi-lo); t = x + relu(0-x); t = t - relu(t-u)
                                   q = R(t/s);                                  y = q*s           */
 #define DLMCQ_FORM_COUNT 5
+/* OR-able into the `q_form` argument of the int8 convolution entry points (the consumer's quantiser evaluated in the
+ * epilogue) when its range is an unsigned byte (0 <= q_lo, q_hi <= 255): the codes are stored as int8 `code - 128`
+ * (each byte ^ 0x80) instead of uint8 `code`.  A consumer then takes them as signed codes (x_is_unsigned = 0) with the
+ * zero point `zp - 128`: the same integers reach the matrix cores (they multiply signed bytes, so uint8 codes are
+ * re-centred on every operand read otherwise), hence the same results.  Accepted by dlmcq_conv2d_i8_nhwc_fused / _asym /
+ * _dual and for the SECOND quantiser of the chain entry points (the first one's codes are read in place by the second GEMM);
+ * every other entry point returns DLMCQ_EINVAL for it. */
+#define DLMCQ_EMIT_SHIFT128 0x100
 
 /* ---- what is written to `y` ---- */
 #define DLMCQ_Y_DEQUANT 0 /* the fake-quantised value y */

@@ -1,5 +1,5 @@
 """The halo-tile 3x3 kernel (csrc/conv3x3_i8.hip: 3x3 / stride 1 / pad 1 layers that emit only their consumer's codes,
-K % 128 == 0) against (a) the float64 convolution of the dequantised operands + the oracle's quantiser and (b) the generic
+K % 64 == 0) against (a) the float64 convolution of the dequantised operands + the oracle's quantiser and (b) the generic
 implicit-GEMM kernel of conv_i8.hip run on the same layer with an fp32 output as well (which keeps it off the halo kernel):
 both kernels add the same exact int32 sums into the same rounding chain, so their codes must agree bit for bit.
 Reference call being replaced: F.conv2d in modules/conv.py:13-19 on the operands of FSPTQuant/base.py:108-109,149-152."""
@@ -25,6 +25,12 @@ SHAPES = [
     (1, 64, 1, 1, 128),        # one pixel: every tap but the centre is border
     (2, 64, 2, 3, 128),
     (7, 64, 9, 13, 128),       # M not a multiple of anything
+    (2, 64, 56, 56, 64),       # ResNet-50 stage 1: 64-wide tile, one chunk (the single-halo-buffer instantiation)
+    (3, 64, 12, 12, 64),
+    (2, 128, 10, 10, 64),      # 64-wide tile, two chunks
+    (1, 64, 6, 70, 64),        # 64-wide, wide image
+    (1, 128, 4, 90, 64),
+    (2, 128, 9, 9, 192),       # K % 128 != 0: three 64-wide column blocks
 ]
 
 
@@ -98,3 +104,61 @@ def test_halo_kernel_border_rows_never_leak():
                          padding=1, emit=emit, want_out=False)
     want = O.fq_zeropoint(bias, torch.tensor(0.01), torch.tensor(100.0), 0, 255)[0].to(torch.uint8)
     assert torch.equal(got.cpu(), want.view(1, k, 1, 1).expand(n, k, h, w))
+
+
+def test_shifted_code_emission_is_the_same_network():
+    """DLMCQ_EMIT_SHIFT128: a producer stores an unsigned-byte quantiser's codes as int8 `code - 128`; the consumer takes them as
+    signed codes with the zero point `zp - 128`.  Producer side: byte for byte `code ^ 0x80` (1x1 swapped kernel, halo kernel,
+    the chain kernel's second quantiser, fp32-output kernel).  Consumer side (halo kernel without its xor, generic kernel):
+    bit-identical results."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator(device=DEV).manual_seed(99)
+    n, c, h, k = 3, 64, 12, 128
+    x = torch.randint(0, 256, (n, c, h, h), generator=g, device=DEV, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+
+    def layer(kk, cc, r):
+        wq = torch.randint(-127, 128, (kk, r, r, cc), generator=g, device=DEV, dtype=torch.int8)
+        return dict(wq=wq, wsum=wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous(), bias=torch.randn(kk, generator=g, device=DEV),
+                    w_scale=torch.rand(kk, generator=g, device=DEV) * 0.002 + 0.0005)
+    l1, l3, l5 = layer(k, c, 1), layer(k, k, 3), layer(512, k, 1)
+    s_in, zp_in = torch.full((1,), 0.02, device=DEV), torch.full((1,), 4.0, device=DEV)
+    q_s, q_z = torch.full((1,), 0.07, device=DEV), torch.full((1,), 9.0, device=DEV)
+
+    def emit(shift):
+        return K.EmitCodes(q_s, q_z, 0, 255, N.FORM_ZEROPOINT, shift128=shift)
+
+    def conv(codes, lay, zp, shift, pad=0, want_out=False, relu=True):
+        return K.conv2d_i8(codes, lay["wq"], lay["wsum"], lay["bias"], s_in, zp, lay["w_scale"], padding=pad, relu=relu, emit=emit(shift),
+                           want_out=want_out)
+    # producers
+    _, u1 = conv(x, l1, zp_in, False)                     # swapped 1x1 kernel
+    _, s1 = conv(x, l1, zp_in, True)
+    assert u1.dtype == torch.uint8 and s1.dtype == torch.int8
+    assert torch.equal(s1.view(torch.uint8), u1 ^ 0x80)
+    o_u, u1o = conv(x, l1, zp_in, False, want_out=True)   # fp32-output kernel (unswapped epilogue)
+    o_s, s1o = conv(x, l1, zp_in, True, want_out=True)
+    assert torch.equal(o_u, o_s) and torch.equal(s1o.view(torch.uint8), u1o ^ 0x80) and torch.equal(u1o, u1)
+    # consumers: the halo kernel (3x3) and the generic kernel (fp32 out) on shifted codes with zp - 128
+    _, u3 = conv(u1, l3, q_z, False, pad=1)
+    _, s3 = conv(s1, l3, q_z - 128.0, False, pad=1)
+    assert torch.equal(u3, s3)
+    _, s3s = conv(s1, l3, q_z - 128.0, True, pad=1)       # halo kernel as a producer of shifted codes
+    assert torch.equal(s3s.view(torch.uint8), u3 ^ 0x80)
+    out_u, _ = conv(u1, l3, q_z, False, pad=1, want_out=True)
+    out_s, _ = conv(s1, l3, q_z - 128.0, False, pad=1, want_out=True)
+    assert torch.equal(out_u, out_s)
+    # the chain kernel's second quantiser
+    a = dict(codes=u3, wq=l5["wq"], wsum=l5["wsum"], bias=l5["bias"], in_scale=q_s, in_zp=q_z, w_scale=l5["w_scale"])
+    l6 = layer(128, 512, 1)
+    b = dict(wq=l6["wq"], wsum=l6["wsum"], bias=l6["bias"], w_scale=l6["w_scale"])
+    res = torch.randn(n, 512, h, h, generator=g, device=DEV).contiguous(memory_format=torch.channels_last)
+    e1 = K.EmitCodes(torch.full((1,), 0.05, device=DEV), torch.zeros(1, device=DEV), 0, 255, N.FORM_ZEROPOINT)
+    _, _, c2u = K.conv2d_i8_chain(a, b, res, relu=True, emit=e1, want_out=True, want_codes=False, relu2=True, emit2=emit(False))
+    _, _, c2s = K.conv2d_i8_chain(a, b, res, relu=True, emit=e1, want_out=True, want_codes=False, relu2=True, emit2=emit(True))
+    assert c2s.dtype == torch.int8 and torch.equal(c2s.view(torch.uint8), c2u ^ 0x80)
+    # the first quantiser of the chain kernel cannot be shifted (its codes are read in place): refused, not mis-computed
+    from dlmc._native import DlmcqError
+    with pytest.raises((DlmcqError, ValueError)):
+        K.conv2d_i8_chain(a, b, res, relu=True, emit=K.EmitCodes(e1.scale, e1.zero_point, 0, 255, N.FORM_ZEROPOINT, shift128=True),
+                          want_out=True, want_codes=True, relu2=True, emit2=emit(False))

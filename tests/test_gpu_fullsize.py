@@ -49,7 +49,10 @@ def _conv_window_ref(codes, s_in, zp, weight_deq, bias, stride, pad, win):
     h0, w0 = p0 * stride - pad, q0 * stride - pad
     h1, w1 = (p0 + ph - 1) * stride - pad + R, (q0 + qw - 1) * stride - pad + S
     ch0, cw0, ch1, cw1 = max(h0, 0), max(w0, 0), min(h1, H), min(w1, W)
-    x = codes[n:n + 1, :, ch0:ch1, cw0:cw1].to("cpu").double()
+    x = codes[n:n + 1, :, ch0:ch1, cw0:cw1].to("cpu")
+    if x.dtype == torch.int8:          # an unsigned quantiser's codes handed over as int8 `code - 128` (DLMCQ_EMIT_SHIFT128)
+        x = x.to(torch.int16) + 128
+    x = x.double()
     x = (x - float(zp)) * float(s_in)                      # x' = (q - zp) * s   (FSPTQuant/base.py:108-109)
     x = F.pad(x, (cw0 - w0, w1 - cw1, ch0 - h0, h1 - ch1))   # padded taps contribute x' = 0
     ref = F.conv2d(x, weight_deq, None if bias is None else bias.double(), stride=stride)
@@ -85,6 +88,8 @@ def _close(got, ref, mag, what):
 def _check_codes(got_codes, fp32_out, ref32, emit, what):
     """got_codes against the oracle's quantiser: exact from the kernel's own fp32 value, +-1 rarely from the reference's."""
     s, z = emit.scale.detach().cpu(), emit.zp.detach().cpu()
+    if got_codes.dtype == torch.int8 and emit.lo >= 0:      # stored as `code - 128` (DLMCQ_EMIT_SHIFT128): compare the codes themselves
+        got_codes = got_codes.to(torch.int16) + 128
     if fp32_out is not None:
         want = O.fq_zeropoint(fp32_out, s, z, emit.lo, emit.hi)[0]
         assert torch.equal(got_codes.float(), want), f"{what}: codes differ from the oracle's codes of the kernel's own fp32 output"

@@ -17,7 +17,7 @@ import torch  # noqa: E402
 
 from dlmc import _native as N  # noqa: E402
 
-CASES = {"c1w": (64, 56, 128), "c2": (128, 28, 128), "c3": (256, 14, 256), "c4": (512, 7, 512)}   # C, H, K
+CASES = {"c1": (64, 56, 64), "c1w": (64, 56, 128), "c2": (128, 28, 128), "c3": (256, 14, 256), "c4": (512, 7, 512)}   # C, H, K
 VARIANTS = {0: "product", 100: "8 waves of 64 x 64", 2: "no weight DMA", 3: "no halo DMA", 4: "no MFMA", 6: "no xor", 7: "no quantiser",
             8: "codes not staged"}
 
@@ -55,7 +55,7 @@ def main():
         trace = torch.zeros(64 * 8 + 6 * 65536, dtype=torch.int64, device=dev)
 
         def run(v, i):
-            bn, adir, wps, res = 128, 5, 0, None
+            bn, adir, wps, res = (128 if k % 128 == 0 else 64), 5, 0, None
             if v == -1:
                 adir = 1                       # the generic kernel
             elif v > 0:
@@ -66,7 +66,7 @@ def main():
                     bn, adir, 0, wps)
             if rc:
                 raise RuntimeError(f"{name} variant {v}: rc {rc}")
-        vs = ([-1] if args.generic else []) + list(VARIANTS)
+        vs = ([-1] if args.generic else []) + [v for v in VARIANTS if v < 100 or k % 128 == 0]
         times = {v: [] for v in vs}
         for v in vs:
             run(v, 0)
@@ -98,7 +98,7 @@ def main():
                 nxt = st[sidx + 1][0] if sidx + 1 < nstep else r[4]
                 print(f"      step {sidx:2d}: {int(r[1] - r[0]):6d} {int(r[2] - r[1]):6d} {int(r[3] - r[2]):6d} {int(r[4] - r[3]):6d}   ({int(nxt - r[0]):6d})")
             fs = (h + 1) * (h + 1)
-            nwg = ((n * fs + 255) // 256) * (k // 128)
+            nwg = ((n * fs + 255) // 256) * (k // (128 if k % 128 == 0 else 64))
             wg = tr[64 * 8:64 * 8 + 6 * nwg].view(nwg, 6)
             pro = (wg[:, 1] - wg[:, 0]).float()
             loop = (wg[:, 2] - wg[:, 1]).float()
