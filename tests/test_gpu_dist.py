@@ -89,7 +89,11 @@ def _run(family, backend):
                 assert torch.equal(res[r][0][k], v), f"rank {r} {k}: {res[r][0][k]} vs {v}"
             else:                        # deeper layers see fp32 convolution outputs, whose last bit MIOpen may change with the batch size
                 torch.testing.assert_close(res[r][0][k], v, rtol=2e-6, atol=0, msg=lambda m: f"rank {r} {k}: {m}")
-            assert torch.equal(res[r][0][k], res[1 - r][0][k]) or not k.startswith("0."), f"ranks disagree on {k}"
+    # rank against rank, EVERY layer, bit for bit: whatever a rank's local convolution produced, the all-reduce leaves the same
+    # [max | -min] on every rank and the scale arithmetic on top of it is deterministic - this is the property the collective
+    # guarantees (the tolerance above concerns only rank against the single-process run, where the batch size differs)
+    for k in want:
+        assert torch.equal(res[0][0][k], res[1][0][k]), f"ranks disagree on {k}: {res[0][0][k]} vs {res[1][0][k]}"
     got = torch.cat([res[0][1], res[1][1]])
     torch.testing.assert_close(got, full, rtol=1e-5, atol=1e-6)
 

@@ -9,7 +9,7 @@ import json
 import pytest
 import torch
 
-from plan_reference import close, emit_codes, node_window_ref, weight_dequant
+from plan_reference import check_node as _check_node, close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -21,51 +21,6 @@ W4A8 = {  # QBase family (quantization_type=None), per-channel extension
 }
 
 
-def _check_node(idx, mod, args, out, full):
-    from dlmc.utils.fuse import DwInt8Layer
-    fp32, codes = out
-    o = fp32 if fp32 is not None else codes
-    if o.dim() == 2:
-        fp32 = None if fp32 is None else fp32[:, :, None, None]
-        codes = None if codes is None else codes[:, :, None, None]
-        o = o[:, :, None, None]
-    lay = mod.layer
-    k = mod.k
-    n_img, _, P, Q = o.shape
-    w_deq = weight_dequant(mod)
-    bias = None if lay.bias is None else lay.bias.detach().float().cpu()
-    dw = isinstance(mod, DwInt8Layer)
-    stride, pad = (lay.stride[0], lay.padding[0]) if lay.weight.dim() == 4 else (1, 0)
-    xin = args[0] if args[0].dim() == 4 else args[0][:, :, None, None]
-    xin = xin[:, :mod.c]                                     # drop the padding channels
-    numel = xin.numel()
-    if xin.dtype == torch.float32:                           # fed by a layer outside the plan: the node quantises its input itself
-        xin = emit_codes(mod.act, xin.float().cpu(), numel).to(torch.uint8)
-    wins = [(n, 0, 0, P, Q) for n in range(n_img)] if full else \
-        [(n, p0, q0, min(5, P), min(5, Q)) for n in (0, n_img - 1) for p0, q0 in ((0, 0), (P - min(5, P), Q - min(5, Q)))]
-    emit_numel = n_img * k * P * Q
-    for win in wins:
-        n, p0, q0, ph, qw = win
-        ref, mag = node_window_ref(xin, mod.act, numel, w_deq, bias, stride, pad, k if dw else 1, win)
-        ref = torch.relu(ref) if mod.relu else ref
-        what = f"node {idx} {type(mod).__name__} {tuple(lay.weight.shape)} window {win}"
-        got32 = None
-        if fp32 is not None:
-            got32 = fp32[n:n + 1, :k, p0:p0 + ph, q0:q0 + qw].cpu()
-            close(got32, ref, mag, what)
-        if codes is not None:
-            got = codes[n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu()
-            if got.shape[1] > k:      # padding channels: the consumer's code of 0
-                pad_code = emit_codes(mod.emit, torch.zeros(1), emit_numel)
-                assert bool((got[:, k:].float() == float(pad_code)).all()), f"{what}: padding channels"
-            if got32 is not None:
-                assert torch.equal(got[:, :k].float(), emit_codes(mod.emit, got32, emit_numel)), f"{what}: codes of the kernel's own fp32 value"
-            else:
-                off = (got[:, :k].float() - emit_codes(mod.emit, ref.float(), emit_numel)).abs()
-                assert float(off.max()) <= 1 and float((off > 0).float().mean()) < 2e-3, \
-                    f"{what}: codes off by {float(off.max())} on {float((off > 0).float().mean()):.2e} of the elements"
-
-
 W8A8_FSPTQ = {  # example/quantization/FSPTQ_config.yaml:40-53 (symmetric per-channel s8 weights, u8 activations)
     "weight": {"enable": True, "type": "minmax_channel", "recon_type": "None", "args": {"n_bits": 8, "signed": True}},
     "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
@@ -73,7 +28,8 @@ W8A8_FSPTQ = {  # example/quantization/FSPTQ_config.yaml:40-53 (symmetric per-ch
 }
 
 
-@pytest.mark.parametrize("family,batch,size,full", [(None, 3, 64, True), (None, 64, 224, False), ("FSPTQ", 3, 64, True)])
+# (None, 1024, 224): BASELINE configs[4] at its stated size - every node on windows of the first and the LAST image
+@pytest.mark.parametrize("family,batch,size,full", [(None, 3, 64, True), (None, 64, 224, False), ("FSPTQ", 3, 64, True), (None, 1024, 224, False)])
 def test_mobileone_s1_w4a8_plan_node_by_node(family, batch, size, full):
     import workloads as W
     from dlmc.utils.fuse import DwInt8Layer, Int8Layer, StemLayer, fuse_inference
@@ -95,10 +51,15 @@ def test_mobileone_s1_w4a8_plan_node_by_node(family, batch, size, full):
     # the 3-channel first layer (matrix cores, with the weight-offset term for the asymmetric W4 weights), 21 units, the classifier
     assert n_dw == 21 and len(recs) == 1 + 21 + 21 + 1 and isinstance(recs[0][0], StemLayer), (n_dw, len(recs), rep)
     assert rep.skipped == [] and rep.stem == 1, rep
+    rates = {}
     for idx, (mod, args, out) in enumerate(recs):
         if mod.layer.weight.dim() == 2:
             continue                         # the classifier reads fp32 features: checked through the logits below
-        _check_node(idx, mod, args, out, full)
+        _check_node(idx, mod, args, out, full, rates=rates)
+    worst = max(rates.values()) if rates else 0.0
+    print(f"mobileone_s1 {family} batch {batch} @{size}: worst off-by-one rate of a codes-only node {worst:.2e} "
+          f"(node {max(rates, key=rates.get) if rates else None})")
+    assert worst <= 1.2e-4, rates            # twice what round 3 measured (5.9e-5 at batch 1024): a drift must not hide under the 2e-3 bound
     # logits against the module path: same codes layer by layer up to fp32 accumulation-order ties
     spread = float(want.std())
     assert float((got - want).abs().mean()) < 0.05 * spread and torch.equal(got.argmax(1), want.argmax(1)) or batch > 8
