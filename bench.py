@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: ResNet-50 W8A8 per-channel fake-quant forward (BASELINE.json configs[2]).
 
-    python bench.py --gpus N --steps K --warmup W [--scaling strong]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--scaling strong] [--model resnet50|repvgg_a1|mobileone_s1|resnet18]
+    N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE come from the environment), or on its own - without
+    WORLD_SIZE in the environment `python bench.py --gpus N` starts that launcher itself as a child process BEFORE anything
+    touches a GPU (the reference spawns its ranks the same way, example/quantization/DDP_RootQ_train.py:30-34), forwards rank 0's
+    JSON line and exits with the child's status.
+    BASELINE configs[3] verbatim: --model repvgg_a1 --scaling strong --global-batch 4096 --gpus 8;
+    configs[4]: --model mobileone_s1 (W4A8 asymmetric per-channel weights, QBase family, 1024 images per GPU).
 
 A step = one forward of the quantised ResNet-50 (54 quantised layers, FSPTQ forms: weights minmax_channel s8, activations
 minmax_tensor u8, BatchNorm folded first as FSPTQuant.py:67 does) over 512 synthetic 224x224 images per GPU, scales frozen
@@ -115,17 +121,77 @@ def cpu_baseline(batch, budget_s=16.0, fold_bn=True, halfnormal=True):
                            "forwards": len(t1)}}
 
 
+W4A8 = {  # BASELINE configs[4]: QBase family (quantization_type=None), asymmetric per-channel u4 weights (ops.py:129-136), u8 activations
+    "weight": {"enable": True, "type": "minmax_channel", "args": {"n_bits": 4, "signed": False}},
+    "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+    "exclude_layers": [], "override_options": [],
+}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run as a CHILD process (this
+    process has not touched a GPU and never will), pass rank 0's JSON line through, return the child's exit status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:                 # rank 0 prints exactly one JSON line; anything else is passed to stderr
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return rc if rc != 0 or line is not None else 1
+
+
+def dry_run(args, world, rank):
+    """--dry-run (CPU, no GPU work; tests/test_bench_launcher.py): the launcher, the rendezvous, the barrier-bracketed timed
+    region, the MAX over ranks and the one JSON line - with an empty step.  The line says so and carries no measurement."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": f"{args.model} fake-quant fwd images/sec", "value": 0.0, "unit": "images/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True,
+                          "scaling": args.scaling, "vs_baseline": None, "dtype": "i8", "data": "dry-run: no GPU work, no measurement",
+                          "config": {"workload": "dry run of the launcher and the rendezvous", "global_batch": args.batch * world,
+                                     "parallelism": f"dp{world} (batch-sharded replicas)", "backend": args.backend}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="images per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling); default 512, mobileone_s1: 1024")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --batch images on every GPU; strong: a fixed global batch (--global-batch, default 4096 = "
                          "BASELINE configs[3]'s 8 x 512) split evenly over the ranks")
     ap.add_argument("--global-batch", type=int, default=4096, help="--scaling strong: images per step over all GPUs")
-    ap.add_argument("--model", default="resnet50", choices=["resnet18", "resnet50", "repvgg_a1"])
+    ap.add_argument("--model", default="resnet50", choices=["resnet18", "resnet50", "repvgg_a1", "mobileone_s1"],
+                    help="resnet50 = BASELINE configs[2] (the headline); repvgg_a1 = configs[3]'s network (FSPTQ W8A8, deploy form); "
+                         "mobileone_s1 = configs[4] (W4A8, asymmetric per-channel weights, QBase family)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: launcher + rendezvous + one (empty) JSON line; CPU tests")
     ap.add_argument("--keep-bn", action="store_true",
                     help="skip the BN folding of the reference's few-shot PTQ flow (FSPTQuant.py:67) and keep BatchNorm layers")
     ap.add_argument("--conv", choices=["int8", "fp32"], default="int8",
@@ -151,18 +217,29 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     args = ap.parse_args()
     args.int8 = args.conv == "int8"
+    if args.batch is None:
+        args.batch = 1024 if args.model == "mobileone_s1" else 512
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))       # (nothing has touched a GPU: importing torch does not)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.scaling == "strong":
+        if args.global_batch % world:
+            sys.exit("bench.py: --global-batch must be a multiple of the number of GPUs")
+        args.batch = args.global_batch // world
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    if args.scaling == "strong":
-        assert args.global_batch % world == 0, "--global-batch must be a multiple of the number of GPUs"
-        args.batch = args.global_batch // world
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -172,10 +249,14 @@ def main():
 
     torch.manual_seed(2333)  # the reference's seed; identical weights on every rank (replicated)
     model = W.MODELS[args.model]().to(dev).eval()
-    if not args.keep_bn:
-        from dlmc.utils.merge_bn import merge_bn
-        model = merge_bn(model, inplace=True, allow_missing=True)   # FSPTQuant.py:67: merge_bn, then quantize_model
-    quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=args.int8)
+    w4a8 = args.model == "mobileone_s1"
+    if w4a8:       # deploy form (no BatchNorm); the W4A8 per-channel configuration runs through the QBase family
+        quantize_model(model, json.loads(json.dumps(W4A8)), None, int8_gemm=args.int8)
+    else:
+        if not args.keep_bn:
+            from dlmc.utils.merge_bn import merge_bn
+            model = merge_bn(model, inplace=True, allow_missing=True)   # FSPTQuant.py:67: merge_bn, then quantize_model
+        quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=args.int8)
     g = torch.Generator(device=dev).manual_seed(2333 + rank)
     x = torch.randn(args.batch, 3, 224, 224, device=dev, generator=g)
     if args.input == "halfnormal":
@@ -208,7 +289,7 @@ def main():
             from dlmc.utils.fuse import fuse_inference
             model = fuse_inference(model)        # scales are frozen from here on (BASELINE configs[2]: steady state)
         single = model
-        if args.fused and args.streams > 1:
+        if args.fused and args.streams > 1 and not w4a8:     # (QBase plans - grad_scale depends on the elements per call - are not split)
             from dlmc.utils.fuse import StreamedPlan
             model = StreamedPlan(model, args.streams)
         for _ in range(args.warmup):
@@ -289,7 +370,9 @@ def main():
     conv_ops = chain_ops = 0
     if conv["ms"] > 0 or chain["ms"] > 0:
         table = W.layer_table(W.MODELS[args.model](), torch.zeros(1, 3, 224, 224))
-        macs = sum(r[4] for r in table if r[3][1] % 64 == 0 and (len(r[3]) == 2 or r[2][1] == r[3][1]))   # the layers on the int8 kernels (dense, C % 64 == 0)
+        dense = lambda r: len(r[3]) == 2 or r[2][1] == r[3][1]     # noqa: E731  (groups = 1)
+        # the layers on the matrix-core kernel: dense, C % 64 == 0 (the plan zero-pads MobileOne's 96-channel tensors: counted as they are)
+        macs = sum(r[4] for r in table if dense(r) and (r[3][1] % 64 == 0 or (w4a8 and r[3][1] > 4)))
         chain_macs = 0
         if chain["ms"] > 0:
             from dlmc.utils.fuse import ChainInt8Layer
@@ -318,6 +401,14 @@ def main():
                              "the fp32 output stream, the 3x3 layers by the MFMA pipeline (see conv_i8.TOPs)", ops=conv_ops)
     else:
         main_roof = fq_roof
+    dw = fam.get("conv_dw", empty)                 # depthwise 3x3 on codes (csrc/conv_dw_i8.hip): MobileOne
+    if args.fused and dw["ms"] > 0:
+        dw_roof = roof("conv_dw", dw, "conv_dw3_i8_kernel (depthwise 3x3 on activation codes, fused ReLU + the consumer's codes)",
+                       "algorithmic bytes per launch = 1 B/elem codes in + 1 B/elem codes out (+ 4 B/elem where an fp32 output is kept)")
+        if dw["ms"] > max(conv["ms"], chain["ms"]):
+            main_roof, second_roof = dw_roof, main_roof
+        elif second_roof is None:
+            second_roof = dw_roof
     if args.fused and max(conv["ms"], chain["ms"]) > fq["ms"] and args.model == "resnet50" and args.batch == 512:
         for r in (main_roof, second_roof):
             if r is None:
@@ -353,17 +444,20 @@ def main():
     qbytes = sum(f["bytes"] for k, f in fam.items() if k.startswith("fq"))
     qms = sum(f["ms"] for k, f in fam.items() if k.startswith("fq"))
     out = {
-        "metric": "ResNet-50 W8A8 fake-quant fwd images/sec" if args.model == "resnet50" else f"{args.model} W8A8 fake-quant fwd images/sec",
+        "metric": "ResNet-50 W8A8 fake-quant fwd images/sec" if args.model == "resnet50" else
+                  f"{args.model} {'W4A8' if w4a8 else 'W8A8'} fake-quant fwd images/sec",
         "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None,
         # the arithmetic of the step: int8 x int8 -> int32 on the matrix cores with fp32 quantise / dequantise (int8 mode), or fp32
         "dtype": "i8" if args.int8 else "f32", "data": "synthetic",
-        "config": {"workload": f"{args.model} W8A8 per-channel fake-quant forward (FSPTQ forms: W minmax_channel s8, "
-                               f"A minmax_tensor u8), {'BatchNorm kept' if args.keep_bn else 'BN folded first as in FSPTQuant.py:67'}, "
+        "config": {"workload": (f"{args.model} W4A8 fake-quant forward (QBase family: W minmax_channel u4 asymmetric per channel, "
+                                f"A minmax_tensor u8), deploy form, " if w4a8 else
+                                f"{args.model} W8A8 per-channel fake-quant forward (FSPTQ forms: W minmax_channel s8, "
+                                f"A minmax_tensor u8), {'BatchNorm kept' if args.keep_bn else 'BN folded first as in FSPTQuant.py:67'}, ") +
                                f"{'fused int8 MFMA conv/linear' if args.int8 else 'fp32 conv of the fake-quantised operands'}, "
                                f"{'frozen execution plan (epilogue-fused ReLU / shortcut / next-layer codes; block end + next 1x1 as one launch; weight codes quantised once at plan build), ' if args.fused else ''}"
-                               f"{str(args.streams) + ' HIP streams per GPU (the ' + str(min(args.profiled_steps, args.steps)) + ' profiled step(s) on one), ' if args.fused and args.streams > 1 else ''}"
+                               f"{str(args.streams) + ' HIP streams per GPU (the ' + str(min(args.profiled_steps, args.steps)) + ' profiled step(s) on one), ' if args.fused and args.streams > 1 and not w4a8 else ''}"
                                f"224x224 {'relu(N(0,1))' if args.input == 'halfnormal' else 'N(0,1)'} pixels, batch {args.batch} per GPU, scales frozen",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},
         **({"first_batch": {"ms": round(first_batch_ms, 2), "images_per_s": round(args.batch * world / (first_batch_ms * 1e-3), 1),
