@@ -416,8 +416,11 @@ extern "C" int dlmcq_l2norm_iterate_f32(const float* x, float* scale, const floa
 
 extern "C" size_t dlmcq_l2out_scratch_bytes(int64_t outer, int64_t channels, int64_t inner) {
   if (outer < 1 || channels < 1 || inner < 1) return 0;
-  const L2Plan p = l2_plan(outer, channels, inner);
-  return (size_t)(p.nseg * channels * 3) * sizeof(float);
+  // enough for either mode of dlmcq_l2out_update_f32: per channel (one row per channel) or per tensor (ONE flat row, whose
+  // segment count can exceed the per-channel plan's: batch 4 x 16 channels x 224 x 224 needs 588 floats against 192)
+  const L2Plan pc = l2_plan(outer, channels, inner), pt = l2_plan(1, 1, outer * channels * inner);
+  const int64_t a = pc.nseg * channels * 3, b = pt.nseg * 3;
+  return (size_t)(a > b ? a : b) * sizeof(float);
 }
 
 extern "C" int dlmcq_l2out_update_f32(const float* out, const float* out_q, float* scale, float* best_scale, float* state,

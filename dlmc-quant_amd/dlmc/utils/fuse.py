@@ -620,7 +620,12 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True):
         # ---- the chain  layer -> (+ shortcut) -> ReLU, each link the sole user of the previous one ----
         chain, last, residual, relu = [node], node, None, False
         users = list(last.users)
-        if spec[4] == "gemm" and len(users) == 1 and _is_add(users[0]) and users[0].args[0] is not users[0].args[1]:   # (the stem kernel has no shortcut input)
+        # (the stem kernel has no shortcut input; a layer whose output channels are zero-padded to a multiple of 64 - MobileNetV2's
+        #  24 / 96 / 160-channel projections, CIFAR ResNets' 16 / 32 - computes a k_pad-wide tile: the k-wide fp32 shortcut does not
+        #  fit it, so the add stays outside the kernel)
+        wn = modules[node.target].weight
+        unpadded = wn.dim() != 4 or wn.shape[0] % 64 == 0
+        if spec[4] == "gemm" and unpadded and len(users) == 1 and _is_add(users[0]) and users[0].args[0] is not users[0].args[1]:
             add = users[0]
             residual = add.args[1] if add.args[0] is last else add.args[0]
             chain.append(add)

@@ -200,6 +200,44 @@ def test_fused_plan_is_bit_identical_to_the_wrappers(arch, qtype, cfg, res, sign
     same(fwd(x * 0.8), want, f"{arch} {qtype} graphed")
 
 
+@pytest.mark.parametrize("ch", [24, 96, 160, 128])
+def test_residual_block_whose_width_is_no_multiple_of_64(ch):
+    """MobileNetV2-style projection widths (24 / 96 / 160) and the fp32 `out[:, :k]` of such a layer used as a later shortcut:
+    the plan pads those layers' output channels to a multiple of 64, so their shortcut adds stay outside the kernel
+    (a k-wide fp32 shortcut does not fit a k_pad-wide tile); 128 channels take the absorbed path.  Either way the plan is
+    bit-identical to the wrappers."""
+    from dlmc.utils.fuse import fuse_inference
+    from dlmc.utils.quantize import quantize_model
+
+    class Narrow(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = torch.nn.Conv2d(64, ch, 1)
+            self.a = torch.nn.Conv2d(ch, 128, 1)
+            self.b = torch.nn.Conv2d(128, ch, 3, padding=1)
+            self.c = torch.nn.Conv2d(ch, 64, 1)
+            self.d = torch.nn.Conv2d(64, ch, 1)
+            self.head = torch.nn.Conv2d(ch, 32, 1)
+
+        def forward(self, x):
+            y = torch.relu(self.stem(x))
+            z = torch.relu(self.b(torch.relu(self.a(y))) + y)      # block 1: shortcut = a padded layer's fp32 output
+            z = torch.relu(self.d(torch.relu(self.c(z))) + z)      # block 2: shortcut = the first block's result
+            return self.head(z)
+    torch.manual_seed(7 + ch)
+    net = Narrow().to(DEV).eval()
+    quantize_model(net, FSPTQ, None, "FSPTQ", int8_gemm=True)
+    x = torch.relu(torch.randn(3, 64, 12, 12, device=DEV))
+    with torch.no_grad():
+        net(x)
+        want = net(x * 0.7)
+        fused = fuse_inference(net)
+        got = fused(x * 0.7)
+    rep = fused.fusion_report
+    assert rep.skipped == [] and rep.layers == 6 and rep.residual == (2 if ch % 64 == 0 else 0), rep
+    same(got, want, f"narrow residual block, {ch} channels")
+
+
 STEM_CASES = [  # N, C, H, W, K, R, S, stride, pad
     (2, 3, 32, 32, 64, 7, 7, 2, 3),      # ResNet
     (3, 3, 17, 23, 64, 3, 3, 2, 1),      # RepVGG / MobileOne stage0, odd sizes

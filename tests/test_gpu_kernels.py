@@ -644,3 +644,24 @@ def test_rootq_weight_backward_matches_autograd_of_the_reference_chain():
         torch.testing.assert_close(l2[0].grad, leaves[0].grad, rtol=2e-4, atol=2e-5)
         for a, b in zip(l2[1:], leaves[1:]):
             assert abs(float(a.grad) - float(b.grad)) <= 2e-4 * abs(float(b.grad)) + 1e-5 * scale
+
+
+def test_output_aware_scale_small_batch_few_channels_large_map():
+    """quantize_l2norm_output (ops.py:85-109) on an output of [2, 16, 224, 224]: per tensor, the fused update reduces ONE flat
+    row whose segment count exceeds the per-channel plan's (round 2 sized the scratch for the per-channel plan only and the
+    entry point refused the call with DLMCQ_ESCRATCH).  Against the oracle's loop, same iteration count."""
+    import torch.nn.functional as F
+    from dlmc.quantization.scalar import ops
+
+    class Layer:                       # what the estimator needs of a wrapper: _forward_func (modules/conv.py:13-19)
+        def _forward_func(self, x, w):
+            return F.conv2d(x, w, None, 1, 1)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 3, 224, 224, generator=g)
+    w = torch.randn(16, 3, 3, 3, generator=g) * 0.2
+    conv = torch.nn.Conv2d(3, 16, 3, padding=1, bias=False)
+    s_ref, _ = O.l2norm_output(conv, x, w, 4, True, patience=8)
+    s, _ = ops.quantize_l2norm_output(x.to(DEV), w.to(DEV), Layer(), 4, True, patience=8)
+    torch.testing.assert_close(s.cpu().reshape(()), s_ref.reshape(()), rtol=2e-4, atol=0)
+    s_ch, _ = ops.quantize_l2norm_output_channel(x.to(DEV), w.to(DEV), Layer(), 4, True, patience=4)      # the per-channel plan still fits
+    assert s_ch.shape == (16, 1, 1, 1) and bool(torch.isfinite(s_ch).all())

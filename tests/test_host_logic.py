@@ -188,6 +188,24 @@ def test_fusion_decisions_without_a_gpu():
     with pytest.raises(RuntimeError):
         fuse_inference(calibrated(W.resnet18()).train(), dry_run=True)
 
+    # a residual block whose width is no multiple of 64 (MobileNetV2-style 96-channel projection): the plan pads the layer's output
+    # channels to 128, so its shortcut add is NOT absorbed into the kernel (the k-wide fp32 shortcut would not fit the padded tile)
+    class Narrow(torch.nn.Module):
+        def __init__(self, ch):
+            super().__init__()
+            self.stem = torch.nn.Conv2d(64, ch, 1)
+            self.a = torch.nn.Conv2d(ch, 128, 1)
+            self.b = torch.nn.Conv2d(128, ch, 1)
+            self.head = torch.nn.Conv2d(ch, 64, 1)
+
+        def forward(self, x):
+            y = self.stem(x)
+            return self.head(torch.relu(self.b(torch.relu(self.a(y))) + y))
+    rep = fuse_inference(calibrated(Narrow(96)), dry_run=True).fusion_report
+    assert (rep.layers, rep.residual) == (4, 0), rep
+    rep = fuse_inference(calibrated(Narrow(128)), dry_run=True).fusion_report
+    assert (rep.layers, rep.residual) == (4, 1), rep
+
 
 def test_fuse_reports_untraceable_models():
     from dlmc.utils.fuse import fuse_inference
