@@ -29,7 +29,8 @@ One JSON line on rank 0.  Besides the contract fields:
                        says so: counters cannot be read from inside the process)
   roofline_second_kernel  the same for the other int8 kernel (csrc/conv_i8.hip: 3x3s, stage 3 / 4 block ends, first 1x1s, fc)
   first_batch          one more calibrating forward (every observer re-armed): SURVEY 8(d)'s "first batch, observer on" (module
-                       path; includes one device-to-host read per layer - is the zero point an integer? - that serialises launches)
+                       path: the wrappers' own kernels + torch's ReLU / add between them; the one host read per layer - is the
+                       zero point an integer? - costs 1.7 of its ~30 ms, tools/first_batch_probe.py)
   roofline_fake_quant  the stand-alone fake-quant kernel, measured live on BASELINE configs[1]'s tensor
   quant_work_8d        SURVEY.md 8(d)'s own accounting of the step: the bytes the reference's fake-quant passes move for this
                        batch (8 B per fake-quantised activation / weight element) over the WHOLE step's time, against 8 TB/s.
@@ -462,7 +463,8 @@ def main():
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},
         **({"first_batch": {"ms": round(first_batch_ms, 2), "images_per_s": round(args.batch * world / (first_batch_ms * 1e-3), 1),
                             "what": "one forward with every observer on (module path: min/max pass and all-reduce(MAX) per activation "
-                                    "quantiser, per-channel weight scales, one host read of the zero point per layer, then the layer); not part of `value`"}}
+                                    "quantiser, per-channel weight scales, one host read of the zero point per layer, then the layer, "
+                                    "torch ReLU / add between layers); not part of `value`"}}
            if first_batch_ms is not None else {}),
         "roofline": main_roof,
         **({"roofline_second_kernel": second_roof} if second_roof else {}),

@@ -191,6 +191,17 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     }
 #endif
   }
+  int cstep = 256;       // byte distance between a row's consecutive 64-channel chunks
+#ifdef DLMCQ_LAB
+  if (a.lab & 64) {      // timing only: the fp32 tensors in 64 x 64 blocks (every chunk of a tile one contiguous 16 KB)
+    cstep = 64 * 256;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int lr = wr * 32 + 8 * g + 4 * hsel + b4;
+      fo[g] = lr < rows_here ? (int)(row0 * a.KD * 4 + lr * 256 + (wc * 32 + q4 * 4) * 4) : CH_BIG;
+    }
+  }
+#endif
   const int nst = (a.out ? 4 : 0) + (a.codes ? 1 : 0);   // stores per wave per chunk
 
   // ---- DMA sources.  A wave-instruction lands 16 rows x 64 B; row r of a unit keeps its 16-byte segments XOR-swizzled ----
@@ -219,17 +230,22 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   auto request = [&](int n, auto par_c) {    // everything chunk n needs from memory
     constexpr int P = decltype(par_c)::value;
     int8_t* wb = lds + P * WCH;
+    bool wdma = true;
+#ifdef DLMCQ_LAB
+    // timing only: no weight DMA on odd chunks (16: what a tile of twice the pixels would request per output) / at all (32)
+    wdma = !(((a.lab & 16) && (n & 1)) || (a.lab & 32));
+#endif
 #pragma unroll
     for (int s = 0; s < S1; ++s)
-      __builtin_amdgcn_global_load_lds((gptr_t)(w1p + (int64_t)n * 64 * C1 + s * 64), (lptr_t)(wb + s * 4096 + wave * 1024), 16, 0, 0);
+      if (wdma) __builtin_amdgcn_global_load_lds((gptr_t)(w1p + (int64_t)n * 64 * C1 + s * 64), (lptr_t)(wb + s * 4096 + wave * 1024), 16, 0, 0);
 #pragma unroll
     for (int u = 0; u < U3; ++u)
-      __builtin_amdgcn_global_load_lds((gptr_t)(w3p + (int64_t)u * 64 * a.KD + n * 64), (lptr_t)(wb + (S1 + S2 + u) * 4096 + wave * 1024), 16, 0, 0);
+      if (wdma) __builtin_amdgcn_global_load_lds((gptr_t)(w3p + (int64_t)u * 64 * a.KD + n * 64), (lptr_t)(wb + (S1 + S2 + u) * 4096 + wave * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(parp + n * 64), (lptr_t)(par0 + P * PAR + wave * 256), 4, 0, 0);
     if constexpr (DUALH) {
 #pragma unroll
       for (int s = 0; s < S2; ++s)
-        __builtin_amdgcn_global_load_lds((gptr_t)(w2p + (int64_t)n * 64 * C2 + s * 64), (lptr_t)(wb + (S1 + s) * 4096 + wave * 1024), 16, 0, 0);
+        if (wdma) __builtin_amdgcn_global_load_lds((gptr_t)(w2p + (int64_t)n * 64 * C2 + s * 64), (lptr_t)(wb + (S1 + s) * 4096 + wave * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(parp2 + n * 64), (lptr_t)(par0 + P * PAR + 1024 + wave * 256), 4, 0, 0);
       return;      // no fp32 shortcut tile
     }
@@ -238,7 +254,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 #ifdef DLMCQ_LAB
       if (a.lab & 1) continue;
 #endif
-      bload16(res[P][g], fo[g] + n * 256, r_res);
+      bload16(res[P][g], fo[g] + n * cstep, r_res);
     }
   };
 
@@ -326,7 +342,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
       f32x4 y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
       if constexpr (!DUALH) y = y + res[P][g];
       if (ep1.relu) y = relu4_nan(y);
-      const int off = fo[g] + n * 256;
+      const int off = fo[g] + n * cstep;
       if (a.out) bstore16(y, off, r_out);
       const uint32_t c = eq1.code4(y);
       const int R = wr * 32 + 8 * g + 4 * hsel + b4;
