@@ -103,10 +103,20 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   constexpr int WCH = (S1 + S2 + U3) * 4096;  // bytes of one chunk's weights
   constexpr int NPD = DUALH ? 2 : 1;     // constant-table DMAs per wave per chunk
   constexpr int PAR = NPD * 4 * 256;     // per-channel constants of one chunk ((scale, code sum, bias) per pair) x 64 columns
-  __shared__ __attribute__((aligned(1024))) int8_t lds[2 * WCH + 2 * PAR + 4096 + 3 * KB * 4];
+#ifndef DLMCQ_CHAIN_LDS_T
+#define DLMCQ_CHAIN_LDS_T 0     // (measured in round 3, same box, whole plan: every chain within +-1 % of the DPP form - the kernel is not bound by its vector-instruction count)
+#endif
+  // LDST: the accumulator layout (lane = channel, register = row) is turned into rows of 4 consecutive channels per lane through a
+  // wave-private 1 KB LDS stage per group of 8 rows (4 ds_write_b32 + 1 ds_read_b128, conflict-free with the XOR swizzle below; LDS
+  // operations of one wave execute in order, so neither a barrier nor a wait separates the writes from the read) instead of two DPP
+  // exchange rounds (8 v_mov_dpp + 8 v_cndmask per 4 values: a quarter of the epilogue's vector instructions, which are what
+  // bounds the chains that are not HBM-bound)
+  constexpr bool LDST = DLMCQ_CHAIN_LDS_T != 0;
+  __shared__ __attribute__((aligned(1024))) int8_t lds[2 * WCH + 2 * PAR + 4096 + 3 * KB * 4 + (LDST ? 4096 : 0)];
   int8_t* const par0 = lds + 2 * WCH;
   int8_t* const ctile = lds + 2 * WCH + 2 * PAR;
   int8_t* const par3 = ctile + 4096;     // GEMM 2's per-channel constants, ready-made: s_in * s_w[k] | (128 - zp) * SUM qw[k] | bias[k]
+  float* const tstage = reinterpret_cast<float*>(par3 + 3 * KB * 4) + (threadIdx.x >> 6) * 256;   // this wave's 8 rows x 32 channels
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
@@ -202,6 +212,12 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     }
   }
 #endif
+  // transposition stage: row 4 hsel + j of a group holds this lane's register 4 g + j at column l31; a lane reads back row
+  // 4 hsel + b4, columns 4 q4 .. + 3; 4-column slot c of row r sits at slot c ^ (r & 7)
+  int tw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tw[j] = (4 * hsel + j) * 32 + ((l31 & 3) | ((l31 & ~3) ^ ((4 * hsel + j) * 4)));
+  const int trd = (4 * hsel + b4) * 32 + ((4 * q4) ^ ((4 * hsel + b4) * 4));
   const int nst = (a.out ? 4 : 0) + (a.codes ? 1 : 0);   // stores per wave per chunk
 
   // ---- DMA sources.  A wave-instruction lands 16 rows x 64 B; row r of a unit keeps its 16-byte segments XOR-swizzled ----
@@ -338,8 +354,15 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
-      f32x4 y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      f32x4 y;
+      if constexpr (LDST) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tstage[tw[j]] = v[4 * g + j];
+        y = *reinterpret_cast<const f32x4*>(tstage + trd);
+      } else {
+        quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
+        y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      }
       if constexpr (!DUALH) y = y + res[P][g];
       if (ep1.relu) y = relu4_nan(y);
       const int off = fo[g] + n * cstep;
