@@ -306,28 +306,36 @@ struct StemPoolGeom {
 
 
 template <int R>
-__global__ __launch_bounds__(256) void conv_stem_pool_i8_kernel(const uint8_t* __restrict__ x, const int8_t* __restrict__ w,
+__global__ __launch_bounds__(256, 3) void conv_stem_pool_i8_kernel(const uint8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                 float* __restrict__ out, const float* __restrict__ bias,
                                                                 const int32_t* __restrict__ wsum, const float* __restrict__ s_in,
                                                                 const float* __restrict__ zp_in, const float* __restrict__ s_w,
                                                                 StemPoolGeom g, int shift, ConvEpi ep) {
   __shared__ __attribute__((aligned(16))) int region[SP_TILES * 32 * SP_LD];   // conv pixels x 64 channels: the int32 sums (+ corr)
+  // The filter bank (R rows x 64 channels x 32 bytes) lives in LDS, not in 8 R registers per lane: 136 instead of 192
+  // registers = three waves per SIMD instead of two, in a kernel whose items are short chains of dependent phases
+  // (operands -> 14 MFMAs -> LDS -> barrier -> pool -> barrier).  16-byte half h of channel k sits at slot h ^ (k >> 3 & 1):
+  // conflict-free ds_read_b128 for a fragment read (lane = channel, 32-byte rows).
+  __shared__ i32x4 wbank[R * 64 * 2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hsel = lane >> 5;
+  for (int i = threadIdx.x; i < R * 64 * 2; i += 256) {
+    const int r = i >> 7, k = (i >> 1) & 63, h = i & 1;
+    wbank[(r * 64 + k) * 2 + (h ^ ((k >> 3) & 1))] =
+        k < g.K ? *reinterpret_cast<const i32x4*>(w + ((int64_t)k * R + r) * 32 + h * 16) : i32x4{0, 0, 0, 0};
+  }
+  __syncthreads();
   const uint32_t xorw = shift ? 0x80808080u : 0u;
   const float zpf = zp_in ? zp_in[0] : 0.0f;
   const int zpi = (int)__builtin_rintf(zpf);
   const float sin = s_in[0];
   const EpiQuant eq(ep);
-  i32x4 bf[R][2];
+  const i32x4* const bfp = wbank + (lane & 31) * 2 + (hsel ^ ((lane >> 3) & 1));     // + (r * 64 + j * 32) * 2
   float mult[2], bv[2];
   int corr[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int k = j * 32 + (lane & 31);
     const bool ok = k < g.K;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      bf[r][j] = ok ? *reinterpret_cast<const i32x4*>(w + ((int64_t)k * R + r) * 32 + hsel * 16) : i32x4{0, 0, 0, 0};
     mult[j] = ok ? sin * s_w[k] : 0.0f;
     corr[j] = ok ? (shift - zpi) * wsum[k] : 0;
     bv[j] = (ok && bias) ? bias[k] : 0.0f;
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_stem_pool_i8_kernel(const uint8_t* _
     for (int r = 0; r < R; ++r) {
       const i32x4 a = i32x4{(int)(af[b][r].x ^ xorw), (int)(af[b][r].y ^ xorw), (int)(af[b][r].z ^ xorw), (int)(af[b][r].w ^ xorw)};
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[r][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bfp[(r * 64 + j * 32) * 2], acc[j], 0, 0, 0);
     }
     fetch(work + 2 * gridDim.x, b_c);                // the operands of the item after next
     // which of this tile's pixels exist: row r of the accumulator is pixel wave*32 + r, owned by lane r of each half-wave
