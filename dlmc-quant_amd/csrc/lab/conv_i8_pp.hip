@@ -15,13 +15,13 @@
 //   * EVERY vector-memory load is inline asm that the compiler does not see, counted in one software counter: vmcnt
 //     retires in order, so "wait for load X" is  s_waitcnt vmcnt(ops issued since X)  - beside an LDS-DMA in flight
 //     hipcc would otherwise drain the queue (vmcnt(0)) at the first use of any load it knows about;
-//   * every such load lands in an explicitly named accumulator register (agpr_asm.h) and is moved to a VGPR only after
+//   * every such load lands in an explicitly named accumulator register (lab/agpr_asm.h) and is moved to a VGPR only after
 //     its wait: a register the compiler allocates may be copied, spilled or re-used while the load is still in flight
 //     (tools/lint_agpr.py checks the compiled listing: no compiler access to those registers, no spills).
 // Stores stay ordinary (the compiler never waits for a store); they are NOT counted, which only makes a wait that
 // follows an epilogue conservative.
 #include "../conv_i8_common.h"
-#include "../agpr_asm.h"
+#include "agpr_asm.h"
 
 namespace dlmcq {
 
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, WPS) void conv_i8_pp_kernel(const int8_t* __re
   constexpr int GROUP = BI + KS;                      // vector-memory operations per K step per wave
   constexpr int NSEG = DUAL ? 2 : 1;
   static_assert(BN == 64 || BN == 128, "tile width");
-  // accumulator-register map (agpr_asm.h), counted DOWN from a255 (the compiler allocates upwards from a0): what is in
+  // accumulator-register map (lab/agpr_asm.h), counted DOWN from a255 (the compiler allocates upwards from a0): what is in
   // flight lives here, out of the compiler's reach
   constexpr int AQ_RES = 0;                            // quads: the fp32 shortcut tile, NH passes x 8 rows (not in DUAL kernels)
   constexpr int AQ_FRAG = DUAL ? 0 : NH * 8;           // quads: A fragments, NBUF slots x KS

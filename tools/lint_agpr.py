@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time lint for kernels that keep in-flight loads in hand-named accumulator registers (csrc/agpr_asm.h).
+"""Build-time lint for kernels that keep in-flight loads in hand-named accumulator registers (csrc/lab/agpr_asm.h).
 
 For every kernel of a device assembly listing (hipcc --cuda-device-only -S) it checks that
   * nothing is spilled to scratch (a spill of a register whose load is still in flight stores garbage), and

@@ -70,16 +70,17 @@ for mod, args, out, s, e in recs:
         o = out[2]
         m_ = o.numel() // o.shape[1]
         macs = m_ * (w1.numel() + w3.numel())
-        nb = args[0].numel() + w1.numel() + w3.numel() + m_ * w1.shape[0] * (4 * (out[0] is not None) + (out[1] is not None)) + o.numel()
+        xm, xs = (args[1], args[0]) if mod.swapped else (args[0], args[1])     # (a swapped dual chain reads its main operand second)
+        nb = xm.numel() + w1.numel() + w3.numel() + m_ * w1.shape[0] * (4 * (out[0] is not None) + (out[1] is not None)) + o.numel()
         what = f"+ fp32 shortcut {tuple(args[1].shape)}"
         if mod.short is not None:
             w2 = mod.short.layer.weight
             macs += m_ * w2.numel()
-            nb += args[1].numel() // (mod.short.layer.stride[0] ** 2) + w2.numel()
-            what = f"+ {tuple(args[1].shape)} x {tuple(w2.shape)}"
+            nb += xs.numel() // (mod.short.layer.stride[0] ** 2) + w2.numel()     # the strided shortcut convolution samples 1 / stride^2 of its input
+            what = f"+ {tuple(xs.shape)} x {tuple(w2.shape)}"
         else:
             nb += m_ * w1.shape[0] * 4
-        print(f"{us:8.1f} us  CHAIN {str(tuple(args[0].shape)):20s} x {str(tuple(w1.shape)):18s} {what:42s} -> x {str(tuple(w3.shape)):18s} "
+        print(f"{us:8.1f} us  CHAIN {str(tuple(xm.shape)):20s} x {str(tuple(w1.shape)):18s} {what:42s} -> x {str(tuple(w3.shape)):18s} "
               f"{'out ' if out[0] is not None else '    '}{'codes ' if out[1] is not None else '      '}{2 * macs / us / 1e6:6.0f} TOP/s {nb / us / 1e3:6.0f} GB/s")
         continue
     if isinstance(mod, DualInt8Layer):
