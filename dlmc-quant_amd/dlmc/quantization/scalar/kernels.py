@@ -781,10 +781,19 @@ def pack_int4(codes):
     return packed
 
 
-def unpack_int4(packed, n, signed):
+def unpack_int4(packed, n, signed, out=None):
+    """Packed 4-bit codes (element 2i in the low nibble) -> one byte per code (dlmcq_unpack_int4).  `out`: an int8 / uint8 buffer
+    of >= n elements to expand into (the frozen plan expands all its 4-bit weights into one scratch buffer per step)."""
     N.require_gpu(packed)
-    codes = torch.empty(n, dtype=torch.int8, device=packed.device)
-    N.check(N.lib.dlmcq_unpack_int4(N.ptr(packed.contiguous()), N.ptr(codes), n, int(bool(signed)), N.stream_ptr()))
+    if out is None:
+        codes = torch.empty(n, dtype=torch.int8, device=packed.device)
+    else:
+        N.require_gpu(out)
+        if out.numel() < n or out.element_size() != 1 or not out.is_contiguous():
+            raise ValueError("unpack_int4: out must be a contiguous byte tensor of at least n elements")
+        codes = out.view(torch.int8)
+    PROFILE.launch("unpack_int4", (n + 1) // 2 + n,
+                   lambda: N.check(N.lib.dlmcq_unpack_int4(N.ptr(packed.contiguous()), N.ptr(codes), n, int(bool(signed)), N.stream_ptr())))
     return codes if signed else codes.view(torch.uint8)
 
 

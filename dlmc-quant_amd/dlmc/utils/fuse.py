@@ -565,8 +565,74 @@ def _pool_params(node, modules):
     return k, s, p
 
 
-def fuse_inference(model, report=None, dry_run=False, chain_pairs=True):
+class PackedWeights4(nn.Module):
+    """The plan's 4-bit weight codes as they are stored: two codes per byte (`dlmcq_pack_int4`: element 2i in the low nibble),
+    every layer's codes in the plan's own layout (KRSC / RSC / first-layer), concatenated.  The int8 kernels read one byte per
+    code, so each forward starts with ONE `dlmcq_unpack_int4` launch that expands the whole network's weights into a scratch
+    buffer the plan nodes' `wq` tensors are views of (BASELINE configs[4]: "sub-byte pack/unpack" on the timed path; MobileOne-S1:
+    2.4 MB packed, ~3 us per step).  `expand()` is idempotent: concurrent streams write identical bytes."""
+
+    def __init__(self, nodes, signed):
+        super().__init__()
+        self.signed = bool(signed)
+        sizes = [n.wq.numel() for n in nodes]
+        offs, total = [], 0
+        for sz in sizes:
+            offs.append(total)
+            total += (sz + 31) // 32 * 32                     # 16 packed bytes: the kernels want 16-byte-aligned weights
+        dev = nodes[0].wq.device
+        flat = torch.zeros(total, dtype=torch.int8, device=dev)
+        for n, o, sz in zip(nodes, offs, sizes):
+            flat[o:o + sz] = n.wq.reshape(-1)
+        self.register_buffer("packed", K.pack_int4(flat), persistent=False)
+        self.register_buffer("scratch", torch.empty(total, dtype=torch.int8, device=dev), persistent=False)
+        self.n = total
+        for n, o, sz in zip(nodes, offs, sizes):              # the nodes keep no copy of their own: `wq` becomes a view of the scratch
+            n._buffers["wq"] = self.scratch[o:o + sz].view(n.wq.shape)
+        self.expand()
+
+    def expand(self):
+        K.unpack_int4(self.packed, self.n, self.signed, out=self.scratch)
+
+
+def _pack_plan_weights(gm):
+    """Store every plan node's weight codes whose range fits 4 bits packed (see PackedWeights4).  Returns the holders."""
+    groups = {True: [], False: []}
+    for m in gm.modules():
+        if isinstance(m, _PlanLayer) and hasattr(m, "wq") and m.wq.dtype == torch.int8 and -8 <= m.w_lo and m.w_hi <= 15:
+            lo, hi = int(m.wq.min()), int(m.wq.max())          # (plan build time: one read per layer)
+            if 0 <= lo and hi <= 15:
+                groups[False].append(m)
+            elif -8 <= lo and hi <= 7:
+                groups[True].append(m)
+    holders = [PackedWeights4(nodes, signed) for signed, nodes in groups.items() if nodes]
+    for i, h in enumerate(holders):
+        gm.add_module(f"_packed_weights_{i}", h)
+    if holders:
+        gm.register_forward_pre_hook(lambda mod, args: [h.expand() for h in holders] and None)
+    return holders
+
+
+def _codes_from_blob(mod_name, blob, layer):
+    """A layer's integer weight codes [K, C, R, S] (int16, on the layer's device) from an integer checkpoint of
+    dlmc.utils.export (packed int4 or int8), expanded ON THE DEVICE - the plan never sees fp32 weights for that layer."""
+    rec = blob["layers"].get(mod_name)
+    if rec is None:
+        return None
+    dev = layer.weight.device
+    n = int(torch.tensor(rec["shape"]).prod())
+    if rec["packed_int4"]:
+        q = K.unpack_int4(rec["codes"].to(dev), n, rec["lo"] < 0)
+    else:
+        q = rec["codes"].to(dev)
+    return q.reshape(rec["shape"]).to(torch.int16)
+
+
+def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int4=True, weight_blob=None):
     """Return a `torch.fx.GraphModule` executing `model`'s calibrated quantised forward as the fused int8 plan.
+    `pack_int4`: weight codes whose range fits 4 bits are stored packed and expanded by one launch per forward (PackedWeights4).
+    `weight_blob`: an integer checkpoint (`dlmc.utils.export.export_quantized_state`) of the same model - the plan takes the
+    layers' weight codes from it (expanded on the device) instead of quantising the fp32 weights again.
     Layers that are not eligible (grouped / 3-channel convs, non-integer zero points, RootQ, ...) keep running
     their own wrapper.  `model` must be on the GPU, in eval mode, already calibrated.  `dry_run=True` only takes the
     fusion decisions (graph + `fusion_report`, placeholder nodes): it needs no GPU and the result cannot be run.
@@ -678,6 +744,13 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True):
         if dry_run:       # decisions only (CPU-side tests): the node is a placeholder, nothing is quantised or launched
             gm.add_module(name, _DryNode())
         else:
+            def from_blob(name, sp):       # the layer's weight codes come from the integer checkpoint, expanded on the device
+                if weight_blob is None or name not in weight_blob["layers"]:
+                    return sp
+                return sp[:6] + ((lambda name=name: _codes_from_blob(name, weight_blob, modules[name])),)
+            spec = from_blob(node.target, spec)
+            if other is not None and dual:
+                other = from_blob(residual.target, other)
             plan = cls(modules[node.target], spec, relu=relu, emit=emit, want_out=fp32_needed or emit is None, pool=pool)
             # codes of an unsigned-byte quantiser read only by matrix-core layers (no channel padding, no pooling on the way)
             # travel re-centred (see _PlanLayer.__init__); the consumers recognise them by dtype
@@ -725,6 +798,7 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True):
     gm.recompile()
     if chain_pairs and not dry_run:
         _chain_pass(gm, report)
+    gm.packed_weights = _pack_plan_weights(gm) if (pack_int4 and not dry_run) else []
     gm.fusion_report = report
     return gm
 

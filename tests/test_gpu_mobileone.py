@@ -129,3 +129,51 @@ def test_asymmetric_first_layer_kernel(c, k, r, stride, pad):
     ref = F.conv2d(xd, wd, bias.double(), stride=stride, padding=pad)
     mag = F.conv2d(xd.abs(), wd.abs(), bias.double().abs(), stride=stride, padding=pad)
     close(out.cpu(), ref, mag, f"asym stem c={c} k={k} r={r}")
+
+
+def test_plan_holds_packed_int4_weights_and_loads_the_integer_checkpoint():
+    """BASELINE configs[4] names "sub-byte pack/unpack": the frozen plan stores its 4-bit weight codes two per byte and expands them
+    with ONE dlmcq_unpack_int4 launch per forward (dlmc/utils/fuse.py PackedWeights4); an integer checkpoint of dlmc.utils.export
+    (packed int4, KCRS order) loads into the plan on the device, no fp32 weights involved.  All three plans - unpacked, packed,
+    packed from the checkpoint - give the same bits."""
+    import workloads as W
+    from dlmc.quantization.scalar import kernels as K
+    from dlmc.utils.export import export_quantized_state
+    from dlmc.utils.fuse import _PlanLayer, fuse_inference
+    from dlmc.utils.quantize import quantize_model
+    torch.manual_seed(2333)
+    net = W.mobileone_s1_deploy().to(DEV).eval()
+    quantize_model(net, json.loads(json.dumps(W4A8)), None, None)
+    x = torch.relu(torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(5))).to(DEV)
+    with torch.no_grad():
+        net(x)
+        plain = fuse_inference(net, pack_int4=False)
+        packed = fuse_inference(net)
+        blob = export_quantized_state(net)
+        assert all(rec["packed_int4"] for rec in blob["layers"].values())
+        loaded = fuse_inference(net, weight_blob=blob)
+        want = plain(x * 0.9)
+        K.PROFILE.enabled = True
+        K.PROFILE.reset()
+        got = packed(x * 0.9)
+        K.PROFILE.enabled = False
+        got2 = loaded(x * 0.9)
+    assert [t for t, *_ in K.PROFILE.records].count("unpack_int4") == 1          # one expansion per forward, whole network
+    assert torch.equal(got, want) and torch.equal(got2, want)
+    assert plain.packed_weights == [] and len(packed.packed_weights) == 1
+    holder = packed.packed_weights[0]
+    nodes = [m for m in packed.modules() if isinstance(m, _PlanLayer) and hasattr(m, "wq")]
+    assert len(nodes) == 44
+    lo, hi = holder.scratch.data_ptr(), holder.scratch.data_ptr() + holder.scratch.numel()
+    assert all(lo <= m.wq.data_ptr() < hi for m in nodes)                        # every layer's codes live in the expanded scratch only
+    assert holder.packed.numel() * 2 == holder.scratch.numel()
+    # the same codes whichever way they came: quantised from fp32 at plan build, or expanded from the checkpoint
+    for a, b in zip(nodes, [m for m in loaded.modules() if isinstance(m, _PlanLayer) and hasattr(m, "wq")]):
+        assert torch.equal(a.wq, b.wq)
+    # 8-bit networks are left alone
+    from dlmc.utils.merge_bn import merge_bn
+    r18 = merge_bn(W.resnet18().to(DEV).eval(), inplace=True, allow_missing=True)
+    quantize_model(r18, json.loads(json.dumps(W8A8_FSPTQ)), None, "FSPTQ", int8_gemm=True)
+    with torch.no_grad():
+        r18(torch.relu(torch.randn(2, 3, 64, 64, device=DEV)))
+        assert fuse_inference(r18).packed_weights == []
