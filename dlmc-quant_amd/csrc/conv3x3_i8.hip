@@ -27,12 +27,21 @@
 //     two workgroups = two INDEPENDENT waves per SIMD), or 8 waves of 64 x 64 (2 x 2 blocks; round 3's first version:
 //     its fragment reads, xors and address arithmetic per MFMA are twice as many and its two waves per SIMD run in lockstep).
 //   Vector-memory bytes per K step: 8 KB of weights + 1/9 of a ~20 KB tile for 512 clocks of matrix work per CU: ~20 B/clock.
+//
+//   * STRIDE 2 (S2; a ResNet stage's first 3x3, RepVGG's stage openers).  Split the input into its four PHASE images (even / odd
+//     rows x even / odd columns): output (y, x) reads input rows 2y-1, 2y, 2y+1, i.e. phase row y-1 of the odd rows, y of the even
+//     rows, y of the odd rows - in every phase image the convolution is a stride-1 stencil again, with shifts of 0 or 1 rows and 0
+//     or 1 columns.  The frame is that of the OUTPUT ((P + 1) x (Q + 1), border above and left); tap (r, s) reads phase
+//     (r != 1, s != 1) at frame position q + (r > 0) Wp + (s > 0).  A chunk has four phase tiles of TM + Wp + 2 positions; they
+//     stream through a ring of THREE tile buffers the way the weight slabs do: the nine K steps run phase by phase
+//     (taps 4 | 3 5 | 1 7 | 0 2 6 8) and the tile three ahead is requested as soon as a buffer's last tap has read it.
 #include "conv_i8_common.h"
 
 namespace dlmcq {
 
 struct HaloGeom {
-  int N, H, W, C, K;
+  int N, H, W, C, K;     // H, W: the OUTPUT's (= the input's for stride 1)
+  int Hin, Win;          // the input's
   int Wp, FS;            // W + 1, (H + 1) (W + 1)
   uint32_t MQ;           // N FS: rows of the linear frame space
   int nblk_n;
@@ -43,12 +52,20 @@ struct HaloGeom {
 // LAB (lab library only; results are garbage except for 0 and 1, only the time means something): 1 = clock stamps into `trace`;
 // 2 = no weight DMA, 3 = no halo DMA, 4 = no MFMAs, 6 = no xor of the pixel fragments, 7 = no quantising epilogue,
 // 8 = codes stored straight from the accumulator layout (32-byte pieces, no staging through LDS)
+// K step t of a chunk: which tap's weights (halo_tap), which halo tile (halo_ph: always 0 for stride 1), which shift of it
+// (halo_rs rows, halo_cs columns).  Stride 1: taps in order, shifts (r, s).  Stride 2: phase by phase - taps 4 | 3 5 | 1 7 | 0 2 6 8 -
+// tap (r, s) reading phase (r != 1, s != 1) at shift (r > 0, s > 0).
+constexpr int halo_tap(bool s2, int t) { return !s2 ? t : (t == 0 ? 4 : t == 1 ? 3 : t == 2 ? 5 : t == 3 ? 1 : t == 4 ? 7 : t == 5 ? 0 : t == 6 ? 2 : t == 7 ? 6 : 8); }
+constexpr int halo_ph(bool s2, int t) { return !s2 ? 0 : (t == 0 ? 0 : t <= 2 ? 1 : t <= 4 ? 2 : 3); }
+constexpr int halo_rs(bool s2, int t) { return !s2 ? t / 3 : (halo_tap(true, t) / 3 > 0 ? 1 : 0); }
+constexpr int halo_cs(bool s2, int t) { return !s2 ? t % 3 : (halo_tap(true, t) % 3 > 0 ? 1 : 0); }
+
 // NHB = halo buffers: 2, or 1 for layers with ONE 64-channel chunk (C = 64: nothing to prefetch; the LDS saved buys a third
 // workgroup per CU, whose K loop covers the others' quantising epilogues - at 9 K steps per tile those are most of a tile's life).
 // WPE = waves per SIMD the registers are budgeted for.  XS = the activation codes are uint8 and every pixel fragment is re-centred
 // (^ 0x80) on its way to the matrix cores; producers that emit `code - 128` (DLMCQ_EMIT_SHIFT128) spare this kernel 16 of its ~45
 // vector instructions per K step.
-template <int BN, int TM, int NW, int WC, int HPW, int NHB, int WPE, bool XS, int LAB = 0>
+template <int BN, int TM, int NW, int WC, int HPW, int NHB, int WPE, bool XS, int LAB = 0, bool S2 = false, int HPA = HPW * NW>
 __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, const float* __restrict__ bias, const int32_t* __restrict__ wsum,
     const float* __restrict__ s_in, const float* __restrict__ zp_in, const float* __restrict__ s_w, HaloGeom g, int shift, ConvEpi ep,
@@ -62,7 +79,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
   constexpr int PW = TM / WPX;              // pixels per wave
   constexpr int CW = BN / WC;               // channels per wave
   constexpr int PB = PW / 32, CB = CW / 32; // 32 x 32 MFMA blocks per wave
-  constexpr int HP = HPW * NW;              // halo pieces allocated per buffer
+  constexpr int HP = HPA;                   // halo pieces allocated per buffer (HPW per wave are requested; surplus ones re-load the last)
   constexpr int HALO = HP * 1024;
   constexpr int NBW = SLAB / 1024 / NW;     // weight pieces per wave per step
   constexpr int RING = NBUF * SLAB;
@@ -71,12 +88,11 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
   constexpr int OPER = RING + NHB * HALO;
   constexpr int LDS_BYTES = OPER < STAGE ? STAGE : OPER;
   constexpr int PAR_BYTES = 3 * BN * 4;
-  static_assert(PB >= 1 && CB >= 1 && NBW >= 1 && NBW * NW * 1024 == SLAB && HPW <= 8 && BN % 64 == 0 && (NHB == 1 || NHB == 2), "tile shape");
+  static_assert(PB >= 1 && CB >= 1 && NBW >= 1 && NBW * NW * 1024 == SLAB && HPW <= 8 && BN % 64 == 0 && (S2 ? NHB == 3 : (NHB == 1 || NHB == 2)) && HPA <= HPW * NW, "tile shape");
   __shared__ __attribute__((aligned(1024))) int8_t lds[LDS_BYTES + PAR_BYTES];
   int8_t* const ring = lds;
   int8_t* const halo = lds + RING;
   int8_t* const par = lds + LDS_BYTES;
-
   // XCD-aware tile order (as conv_i8.hip): consecutive tiles - the column blocks of one row block - on one XCD
   const uint32_t nwg = gridDim.x;
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
@@ -125,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
   // logical 16-byte segment s ^ ((p >> 2) & 3) (swizzle on the source side, undone by the fragment reads) ----
   const int lrow = lane >> 2, pslot = lane & 3;
   const int8_t* hsrc[HPW];
-  int hinc[HPW];
+  int hinc[HPW];     // stride 1: bytes to the next chunk (64, or 0 at a border); stride 2: all ones for a pixel, 0 for a border (a mask)
   int hpc[HPW];
 #pragma unroll
   for (int i = 0; i < HPW; ++i) {
@@ -140,13 +156,27 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
     const uint32_t fx = rem - fy * (uint32_t)g.Wp;
     const bool in = n < (uint32_t)g.N && fy >= 1u && fx >= 1u;
     const int seg = pslot ^ ((p >> 2) & 3);
-    hsrc[i] = in ? x + ((int64_t)((n * (uint32_t)g.H + fy - 1u) * (uint32_t)g.W + fx - 1u)) * g.C + seg * 16 : padline;
-    hinc[i] = in ? 64 : 0;
+    if constexpr (S2) {   // phase (0, 0)'s pixel of this frame position: input (2 (fy - 1), 2 (fx - 1)); the other phases are + (a Win + b) C
+      hsrc[i] = in ? x + ((int64_t)((n * (uint32_t)g.Hin + 2u * (fy - 1u)) * (uint32_t)g.Win + 2u * (fx - 1u))) * g.C + seg * 16 : padline;
+      hinc[i] = in ? -1 : 0;
+    } else {
+      hsrc[i] = in ? x + ((int64_t)((n * (uint32_t)g.H + fy - 1u) * (uint32_t)g.W + fx - 1u)) * g.C + seg * 16 : padline;
+      hinc[i] = in ? 64 : 0;
+    }
   }
   auto issue_halo = [&](auto i_c, int buf) {
     constexpr int i = decltype(i_c)::value;
     if (LAB != 3) __builtin_amdgcn_global_load_lds((gptr_t)hsrc[i], (lptr_t)(halo + buf * HALO + hpc[i] * 1024), 16, 0, 0);
     hsrc[i] += hinc[i];
+  };
+  // stride 2: the whole tile of phase `ph` (0: even rows / even columns, 1: even / odd, 2: odd / even, 3: odd / odd) of chunk `c`
+  const int ph_row = g.Win * g.C, ph_col = g.C;
+  auto issue_tile = [&](int ph, int c, int buf) {
+    const int off = (ph >> 1) * ph_row + (ph & 1) * ph_col + c * 64;
+    static_for<HPW>([&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+      if (LAB != 3) __builtin_amdgcn_global_load_lds((gptr_t)(hsrc[i] + (off & hinc[i])), (lptr_t)(halo + buf * HALO + hpc[i] * 1024), 16, 0, 0);
+    });
   };
 
   // ---- weight DMA: piece j of this wave moves slab rows (j * NW + wave) * 16 .. + 15 of every step; slab row d of a 32-row block
@@ -156,13 +186,15 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
   for (int j = 0; j < NBW; ++j) {
     const int drow = (j * NW + wave) * 16 + lrow, d = drow & 31;
     const int k = n0 + (drow & ~31) + 16 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3);
-    wsrc[j] = w + (int64_t)k * (9 * g.C) + (pslot ^ ((drow >> 2) & 3)) * 16;
+    wsrc[j] = w + (int64_t)k * (9 * g.C) + halo_tap(S2, 0) * g.C + (pslot ^ ((drow >> 2) & 3)) * 16;
   }
   const int nchunks = g.C >> 6;
-  const int w_tap = g.C;                       // next tap, same chunk
-  const int w_chunk = 64 - 8 * g.C;            // tap 8 of chunk c -> tap 0 of chunk c + 1
-  auto issue_w = [&](auto slot_c, int inc) {
-    constexpr int SL = decltype(slot_c)::value;
+  // wsrc always points at the next slab to request; after the slab of K step u (tap TAP[u]) it moves to TAP[u + 1]'s, or to
+  // TAP[0] of the next chunk
+  auto issue_w = [&](auto slot_c, auto u_c) {
+    constexpr int SL = decltype(slot_c)::value, u = decltype(u_c)::value;
+    constexpr int dtap = u == 8 ? halo_tap(S2, 0) - halo_tap(S2, 8) : halo_tap(S2, (u + 1) % 9) - halo_tap(S2, u);
+    const int inc = dtap * g.C + (u == 8 ? 64 : 0);
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
       if (LAB != 2) __builtin_amdgcn_global_load_lds((gptr_t)wsrc[j], (lptr_t)(ring + SL * SLAB + (j * NW + wave) * 1024), 16, 0, 0);
@@ -198,8 +230,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
   i32x4 wfA[CB], pfA[PB], wfB[CB], pfB[PB];
   auto read_frags = [&](auto u_c, auto t_c, auto ks_c, const int8_t* hbuf, i32x4 (&wf)[CB], i32x4 (&pf)[PB]) {
     constexpr int U = decltype(u_c)::value, t = decltype(t_c)::value, ks = decltype(ks_c)::value;
-    constexpr int r = t / 3, s = t % 3;
-    const int p0 = pbase + (r == 0 ? 0 : (r == 1 ? tap_r1 : tap_r2)) + s;
+    const int p0 = pbase + (halo_rs(S2, t) == 0 ? 0 : (halo_rs(S2, t) == 1 ? tap_r1 : tap_r2)) + halo_cs(S2, t);
     const int pa = (p0 * 64 + ((hsel ^ ((p0 >> 2) & 3)) << 4)) ^ (ks << 5);     // ((p + 32 jp) >> 2) & 3 = (p >> 2) & 3
     const int8_t* const sb = ring + U * SLAB;
 #pragma unroll
@@ -221,13 +252,19 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
         else acc[jc][jp] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[jc], pf[jp], acc[jc][jp], 0, 0, 0);
       }
   };
-  constexpr int nbw = (LAB == 2 ? 0 : NBW), nhp = (LAB == 3 ? 0 : 1);
+  constexpr int nbw = (LAB == 2 ? 0 : NBW);
 
-  // prologue: chunk 0's tile and the first three slabs; the first wait leaves slabs 1 and 2 in flight
-  static_for<HPW>([&](auto i) { issue_halo(i, 0); });
-  issue_w(std::integral_constant<int, 0>{}, w_tap);
-  issue_w(std::integral_constant<int, 1>{}, w_tap);
-  issue_w(std::integral_constant<int, 2>{}, w_tap);
+  // prologue: chunk 0's tile (stride 2: its first three phase tiles) and the first three slabs; the first wait leaves slabs 1 and 2 in flight
+  if constexpr (S2) {
+    issue_tile(0, 0, 0);
+    issue_tile(1, 0, 1);
+    issue_tile(2, 0, 2);
+  } else {
+    static_for<HPW>([&](auto i) { issue_halo(i, 0); });
+  }
+  issue_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  issue_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  issue_w(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
   if (STAMP && wgt) wgt[1] = __builtin_readcyclecounter();
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * nbw) : "memory");
   if (tid < BN) {
@@ -240,35 +277,60 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
   read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, halo, wfA, pfA);
 
   for (int c = 0; c < (NHB == 1 ? 1 : nchunks); ++c) {
-    const bool more = NHB == 2 && c + 1 < nchunks;
-    const int8_t* const hb = halo + (NHB == 2 ? (c & 1) * HALO : 0);
-    const int8_t* const hb_next = halo + (NHB == 2 ? ((c + 1) & 1) * HALO : 0);
+    const bool more = NHB != 1 && c + 1 < nchunks;
+    // stride 1: the chunk's one tile, double-buffered; stride 2: phase tile p of chunk c lives in buffer (c + p) % 3
+    const int b0 = S2 ? c % 3 : (NHB == 2 ? (c & 1) : 0);
+    auto tile_of = [&](int ph, bool next_chunk) -> const int8_t* {
+      if constexpr (S2) {
+        int b = b0 + ph + (next_chunk ? 1 : 0);
+        b = b >= 6 ? b - 6 : (b >= 3 ? b - 3 : b);
+        return halo + b * HALO;
+      } else {
+        return halo + (NHB == 2 ? ((next_chunk ? c + 1 : c) & 1) * HALO : 0);
+      }
+    };
     static_for<9>([&](auto t_c) {
       constexpr int t = decltype(t_c)::value;
       constexpr int U = t % NBUF;
       stamp(0);
       // phase 0
-      read_frags(std::integral_constant<int, U>{}, t_c, std::integral_constant<int, 1>{}, hb, wfB, pfB);
+      read_frags(std::integral_constant<int, U>{}, t_c, std::integral_constant<int, 1>{}, tile_of(halo_ph(S2, t), false), wfB, pfB);
       multiply(wfA, pfA);
       stamp(1);
       // phase 1
       if (t < 8 || more) {
         // slab s + 1 (requested three steps ago) must have landed; younger and allowed to stay in flight: slab s + 2 (unless the
-        // loop ends before it) and the halo piece step s - 1 requested behind it (steps 1 .. HPW of a chunk with a successor;
-        // never at t = 8: the next step reads the new tile, so everything but the youngest slab must be there).
-        // This wave's reads of slab s are complete (lgkmcnt) before the barrier lets anyone overwrite it.
-        constexpr bool HPREV = t >= 1 && t <= HPW && t <= 7;
-        if (t >= 7 && !more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (HPREV && more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(nbw + nhp) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(nbw) : "memory");
+        // loop ends before it) and whatever halo pieces step s - 1 requested in front of it.  Stride 1: one piece per wave in steps
+        // 0 .. HPW - 1 of a chunk with a successor (never counted at t = 8: the next step reads the new tile, so everything but the
+        // youngest slab must be there).  Stride 2: a whole tile (HPW pieces) in steps 0 (always: this chunk's fourth phase), 2, 4 and
+        // 8 (the next chunk's first three, if there is one).  A tile is read two or more steps after its request, i.e. behind a
+        // wait that has retired it.  This wave's reads of slab s are complete (lgkmcnt) before the barrier lets anyone overwrite it.
+        constexpr int hw = (LAB == 3 ? 0 : (S2 ? HPW : 1));
+        if constexpr (S2) {
+          if (t >= 7 && !more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          else if (t == 1 || (t == 0 && c > 0) || ((t == 3 || t == 5) && more))
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(nbw + hw) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(nbw) : "memory");
+        } else {
+          constexpr bool HPREV = t >= 1 && t <= HPW && t <= 7;
+          if (t >= 7 && !more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          else if (HPREV && more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(nbw + hw) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(nbw) : "memory");
+        }
         stamp(2);
         read_frags(std::integral_constant<int, (U + 1) % NBUF>{}, std::integral_constant<int, (t + 1) % 9>{}, std::integral_constant<int, 0>{},
-                   t == 8 ? hb_next : hb, wfA, pfA);
-        // requests: a piece of the next chunk's tile into the other halo buffer, then slab s + 3 into the slot of slab s
-        if constexpr (t < HPW && NHB == 2) {
+                   tile_of(halo_ph(S2, (t + 1) % 9), t == 8), wfA, pfA);
+        // requests: halo pieces first (see the wait above), then slab s + 3 into the slot of slab s
+        if constexpr (S2) {
+          // the buffer whose last tap has just been read takes the tile three ahead: T(c, 3) at step 0, T(c + 1, 0 / 1 / 2) at 2 / 4 / 8
+          if constexpr (t == 0) issue_tile(3, c, b0);
+          if constexpr (t == 2 || t == 4 || t == 8) {
+            if (more) issue_tile(t == 2 ? 0 : (t == 4 ? 1 : 2), c + 1, (b0 + (t == 2 ? 1 : (t == 4 ? 2 : 0))) % 3);
+          }
+        } else if constexpr (t < HPW && NHB == 2) {
           if (more) issue_halo(t_c, (c + 1) & 1);
         }
-        if (t < 6 || more) issue_w(std::integral_constant<int, U>{}, t == 5 ? w_chunk : w_tap);
+        if (t < 6 || more) issue_w(std::integral_constant<int, U>{}, std::integral_constant<int, (t + 3) % 9>{});
         stamp(3);
       }
       multiply(wfB, pfB);
@@ -362,24 +424,33 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
 // Whether the halo kernel takes this layer (conv_launch asks before it picks a generic tile), and the launch.
 bool conv3x3_halo_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
                           int32_t dilation, const ConvEpi& ep, const float* out, bool dual) {
-  if (R != 3 || S != 3 || stride != 1 || pad != 1 || dilation != 1 || dual || out || ep.residual || ep.w_off || !ep.codes) return false;
+  if (R != 3 || S != 3 || (stride != 1 && stride != 2) || pad != 1 || dilation != 1 || dual || out || ep.residual || ep.w_off || !ep.codes)
+    return false;
   if (C % 64 != 0 || K % 64 != 0 || !aligned16(ep.codes)) return false;
-  if (W + 1 > 120 || N * (H + 1) * (W + 1) + 1024 >= (1ll << 31) || N * H * W * C >= (1ll << 31)) return false;
+  if (stride == 2 && ((H | W) & 1)) return false;                      // (odd sizes: the generic kernel)
+  const int64_t P = H / stride, Q = W / stride;                        // pad 1, 3 x 3: P = H for stride 1, H / 2 for even H at stride 2
+  if (stride == 2 && Q + 1 > 62) return false;                         // a phase tile of 256 + Wp + 2 positions in 20 pieces
+  // measured (plan profiles, batch 512): 256 -> 256 at 28^2 -> 14^2 110 -> 86 us, 512 -> 512 at 14^2 -> 7^2 88 -> 75, 128 -> 128 at
+  // 56^2 -> 28^2 122 -> 115, 64 -> 64 at 112^2 -> 56^2 210 -> 197; a single chunk feeding 128 channels (64 -> 128 at 56^2 -> 28^2) is
+  // all prologue: 80 -> 87, left to the generic kernel
+  if (stride == 2 && C == 64 && K != 64) return false;
+  if (Q + 1 > 120 || N * (P + 1) * (Q + 1) + 1024 >= (1ll << 31) || N * H * W * C >= (1ll << 31)) return false;
   return true;
 }
 
 int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, const int32_t* wsum, const float* in_scale,
                         const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
-                        int shift, const ConvEpi& ep, hipStream_t st, int lab, void* lab_trace) {
+                        int32_t stride, int shift, const ConvEpi& ep, hipStream_t st, int lab, void* lab_trace) {
   constexpr int TM = 256;
   const int bn = K % 128 == 0 ? 128 : 64;
+  const bool s2 = stride == 2;
   HaloGeom g;
-  g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C = (int)C; g.K = (int)K;
-  g.Wp = (int)W + 1;
-  g.FS = (int)((H + 1) * (W + 1));
+  g.N = (int)N; g.Hin = (int)H; g.Win = (int)W; g.H = (int)(H / stride); g.W = (int)(W / stride); g.C = (int)C; g.K = (int)K;
+  g.Wp = g.W + 1;
+  g.FS = (g.H + 1) * (g.W + 1);
   g.MQ = (uint32_t)(N * g.FS);
   g.nblk_n = (int)(K / bn);
-  g.hp = (TM + 2 * g.Wp + 2 + 15) / 16;
+  g.hp = (TM + (s2 ? 1 : 2) * g.Wp + 2 + 15) / 16;
   g.fsdiv = make_fastdiv((uint32_t)g.FS);
   g.wpdiv = make_fastdiv((uint32_t)g.Wp);
   const int64_t nblk_m = ((int64_t)g.MQ + TM - 1) / TM;
@@ -388,9 +459,9 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
   unsigned long long* const trace = static_cast<unsigned long long*>(lab_trace);
 #define DLMCQ_HALO_ARGS(NW) dim3((uint32_t)nwg), dim3(NW * 64), 0, st, x, w, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, trace
 #ifdef DLMCQ_LAB
-  if (lab) {     // lab: variant = lab % 100 on the product tiling, + 100 for the 8-wave tiling (100 = its product code)
+  if (lab) {     // lab: variant = lab % 100 on the product tiling, + 100 for the 8-wave tiling (100 = its product code); stride 1 only
     const int v = lab % 100;
-    if (g.hp > 24 || (v == 1 && !trace)) return DLMCQ_EINVAL;
+    if (s2 || g.hp > 24 || (v == 1 && !trace)) return DLMCQ_EINVAL;
     if (lab >= 100) {
       if (bn != 128) return DLMCQ_EINVAL;
       switch (v) {
@@ -422,11 +493,36 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
 #endif
 #define DLMCQ_HALO_GO(NW, ...)                                                                            \
   do {                                                                                                   \
+    if (shift) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<__VA_ARGS__>), DLMCQ_HALO_ARGS(NW));           \
+    else hipLaunchKernelGGL((conv3x3_halo_i8_kernel<__VA_ARGS__>), DLMCQ_HALO_ARGS(NW));                 \
+  } while (0)
+  if (s2) {
+    // stride 2: three phase-tile buffers of 18 pieces (Wp <= 30: two workgroups per CU at 128 channels) or 20 (Wp <= 62)
+    if (g.hp > 20) return DLMCQ_EINVAL;
+    const bool big = g.hp > 18;
+#define DLMCQ_HALO_S2(BN_, HPA_, WPE_)                                                                                             \
+  do {                                                                                                                            \
+    if (shift) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, 5, 3, WPE_, true, 0, true, HPA_>), DLMCQ_HALO_ARGS(4));   \
+    else hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, 5, 3, WPE_, false, 0, true, HPA_>), DLMCQ_HALO_ARGS(4));        \
+  } while (0)
+    if (bn == 128) {
+      if (!big) DLMCQ_HALO_S2(128, 18, 2);
+      else DLMCQ_HALO_S2(128, 20, 1);      // (87 KB of LDS: one workgroup per CU)
+    } else {
+      if (!big) DLMCQ_HALO_S2(64, 18, 2);
+      else DLMCQ_HALO_S2(64, 20, 2);
+    }
+#undef DLMCQ_HALO_S2
+    return launch_status();
+  }
+  if (g.hp > 32) return DLMCQ_EINVAL;
+  const bool wide = g.hp > 24;        // images wider than 57 pixels: 8 halo pieces per wave, one workgroup per CU
+#undef DLMCQ_HALO_GO
+#define DLMCQ_HALO_GO(NW, ...)                                                                            \
+  do {                                                                                                   \
     if (shift) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<__VA_ARGS__, true>), DLMCQ_HALO_ARGS(NW));    \
     else hipLaunchKernelGGL((conv3x3_halo_i8_kernel<__VA_ARGS__, false>), DLMCQ_HALO_ARGS(NW));         \
   } while (0)
-  if (g.hp > 32) return DLMCQ_EINVAL;
-  const bool wide = g.hp > 24;        // images wider than 57 pixels: 8 halo pieces per wave, one workgroup per CU
   if (bn == 128) {
     if (!wide) DLMCQ_HALO_GO(4, 128, TM, 4, 1, 6, 2, 2);
     else DLMCQ_HALO_GO(4, 128, TM, 4, 1, 8, 2, 1);

@@ -622,7 +622,7 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   const int8_t* xs = reinterpret_cast<const int8_t*>(x);
   const ConvPlan plan = forced ? *forced : conv_plan(C, K, R, S, seg2 != nullptr);
   if (plan.halo && conv3x3_halo_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
-    return conv3x3_halo_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, shift, ep, st);
+    return conv3x3_halo_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st);
   if (plan.bn != 64 && plan.bn != 128 && plan.bn != 256) return DLMCQ_EINVAL;
   // 256-wide tiles exist for the swapped codes-only layers only (one third fewer operand bytes per MAC, two workgroups per CU)
   const bool swap_ok = plan.swap && ep.codes && !out && !ep.residual && K % plan.bn == 0 && aligned16(ep.codes);
@@ -827,7 +827,7 @@ extern "C" int dlmcq_x_conv2d_i8_tuned(const void* x, const int8_t* w, float* ou
     ConvEpi e2 = ep;
     e2.residual = nullptr;
     return conv3x3_halo_launch(reinterpret_cast<const int8_t*>(x), w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K,
-                               x_is_unsigned ? 128 : 0, e2, reinterpret_cast<hipStream_t>(stream), -pp_wps - 100,
+                               stride, x_is_unsigned ? 128 : 0, e2, reinterpret_cast<hipStream_t>(stream), -pp_wps - 100,
                                const_cast<float*>(residual));
   }
   if (pp_wps < 0) {   // what-bounds-the-step variants of the 128-wide direct-A kernel (LAB = -pp_wps)

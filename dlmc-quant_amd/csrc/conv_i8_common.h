@@ -61,12 +61,12 @@ __device__ __forceinline__ void gload16(i32x4& dst, const int8_t* p) {
   asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
 }
 
-// conv3x3_i8.hip: the halo-tile kernel for 3x3 / stride 1 / pad 1 layers that emit only their consumer's codes
+// conv3x3_i8.hip: the halo-tile kernel for 3x3 / stride 1 or 2 / pad 1 layers that emit only their consumer's codes
 bool conv3x3_halo_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
                           int32_t dilation, const ConvEpi& ep, const float* out, bool dual);
 int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, const int32_t* wsum, const float* in_scale,
                         const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
-                        int shift, const ConvEpi& ep, hipStream_t st, int lab = 0, void* lab_trace = nullptr);
+                        int32_t stride, int shift, const ConvEpi& ep, hipStream_t st, int lab = 0, void* lab_trace = nullptr);
 
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {

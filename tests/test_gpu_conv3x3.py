@@ -1,4 +1,4 @@
-"""The halo-tile 3x3 kernel (csrc/conv3x3_i8.hip: 3x3 / stride 1 / pad 1 layers that emit only their consumer's codes,
+"""The halo-tile 3x3 kernel (csrc/conv3x3_i8.hip: 3x3 / stride 1 or 2 / pad 1 layers that emit only their consumer's codes,
 K % 64 == 0) against (a) the float64 convolution of the dequantised operands + the oracle's quantiser and (b) the generic
 implicit-GEMM kernel of conv_i8.hip run on the same layer with an fp32 output as well (which keeps it off the halo kernel):
 both kernels add the same exact int32 sums into the same rounding chain, so their codes must agree bit for bit.
@@ -31,10 +31,19 @@ SHAPES = [
     (1, 64, 6, 70, 64),        # 64-wide, wide image
     (1, 128, 4, 90, 64),
     (2, 128, 9, 9, 192),       # K % 128 != 0: three 64-wide column blocks
+    # stride 2 (four phase images streamed through three tile buffers): ResNet-50's stage openers, RepVGG's
+    (3, 128, 56, 56, 128, 2),  # 56^2 -> 28^2: Wp = 29, 18-piece tiles
+    (2, 256, 28, 28, 256, 2),  # two column blocks, four chunks
+    (3, 512, 14, 14, 512, 2),  # 14^2 -> 7^2: eight chunks, tiles spanning several images
+    (1, 64, 112, 112, 64, 2),  # RepVGG stage 1: Wp = 57, 20-piece tiles, 64-wide column block
+    (2, 64, 56, 56, 128, 2),   # one chunk only
+    (5, 64, 6, 10, 64, 2),
+    (1, 64, 2, 2, 128, 2),     # a single output pixel
+    (1, 128, 4, 120, 128, 2),  # Wp = 61: the widest image the stride-2 kernel takes
 ]
 
 
-def _layer(idx, n, c, h, w, k, unsigned, zp, relu, with_bias):
+def _layer(idx, n, c, h, w, k, unsigned, zp, relu, with_bias, stride=1):
     g = torch.Generator().manual_seed(4242 + idx)
     lo, hi = (0, 255) if unsigned else (-127, 127)
     codes = torch.randint(lo, hi + 1, (n, c, h, w), generator=g).to(torch.uint8 if unsigned else torch.int8)
@@ -44,7 +53,7 @@ def _layer(idx, n, c, h, w, k, unsigned, zp, relu, with_bias):
     bias = torch.randn(k, generator=g) * 0.1 if with_bias else None
     s_in = torch.tensor(0.0231)
     qw, wdeq = O.fq_symmetric(wt, s_w, -127, 127)
-    ref = F.conv2d((codes.double() - zp) * s_in.double(), wdeq.double(), None if bias is None else bias.double(), padding=1)
+    ref = F.conv2d((codes.double() - zp) * s_in.double(), wdeq.double(), None if bias is None else bias.double(), padding=1, stride=stride)
     if relu:
         ref = torch.relu(ref)
     return codes, wt, s_w, bias, s_in, ref
@@ -55,10 +64,12 @@ def test_halo_kernel_vs_float64_and_generic_kernel(unsigned):
     from dlmc import _native as N
     from dlmc.quantization.scalar import kernels as K
     worst = 0.0
-    for idx, (n, c, h, w, k) in enumerate(SHAPES):
+    for idx, shape in enumerate(SHAPES):
+        n, c, h, w, k = shape[:5]
+        stride = shape[5] if len(shape) > 5 else 1
         zp = float(3 + idx) if unsigned else float(idx % 3 - 1)      # non-zero: the borders must read the zero point's code
         relu = idx % 2 == 0
-        codes, wt, s_w, bias, s_in, ref = _layer(idx, n, c, h, w, k, unsigned, zp, relu, idx % 3 != 1)
+        codes, wt, s_w, bias, s_in, ref = _layer(idx, n, c, h, w, k, unsigned, zp, relu, idx % 3 != 1, stride)
         wq, wsum = K.quantize_weight_krsc(wt.to(DEV), s_w.to(DEV), -127, 127)
         if unsigned:
             q_s = (ref.abs().max() / 200).float().reshape(1)         # some saturation
@@ -69,9 +80,9 @@ def test_halo_kernel_vs_float64_and_generic_kernel(unsigned):
         emit = K.EmitCodes(q_s.to(DEV), None if q_z is None else q_z.to(DEV), lo, hi, form)
         cd = codes.to(DEV).contiguous(memory_format=torch.channels_last)
         args = (cd, wq, wsum, None if bias is None else bias.to(DEV), s_in.to(DEV), torch.tensor(zp).to(DEV), s_w.to(DEV))
-        _, got = K.conv2d_i8(*args, padding=1, relu=relu, emit=emit, want_out=False)          # the halo kernel
-        out, gen = K.conv2d_i8(*args, padding=1, relu=relu, emit=emit, want_out=True)         # the generic kernel
-        assert got.shape == (n, k, h, w) and got.is_contiguous(memory_format=torch.channels_last)
+        _, got = K.conv2d_i8(*args, padding=1, stride=stride, relu=relu, emit=emit, want_out=False)          # the halo kernel
+        out, gen = K.conv2d_i8(*args, padding=1, stride=stride, relu=relu, emit=emit, want_out=True)         # the generic kernel
+        assert got.shape == (n, k, h // stride, w // stride) and got.is_contiguous(memory_format=torch.channels_last)
         assert torch.equal(got, gen), f"shape {idx} {SHAPES[idx]}: halo kernel and generic kernel disagree"
         torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-6, atol=2e-5, msg=lambda m: f"shape {idx}: {m}")
         # the oracle's quantiser on the float64 result: int32-exact accumulation vs float64 may differ by one code at a tie

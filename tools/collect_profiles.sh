@@ -15,9 +15,18 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- pyt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/fetch.log" 2>&1 || echo "fetch pass failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/write.log" 2>&1 || echo "write pass failed"
 cd "$GRAFT_REPO_ROOT"
-python3 tools/pmc_summary.py --tail conv_chain_i8_kernel 11 --tail conv_i8_mfma_kernel 27 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
+python3 tools/pmc_summary.py --tail conv_chain_i8_kernel 11 --tail conv_i8_mfma_kernel 14 --tail conv3x3_halo_i8_kernel 13 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
 python3 tools/plan_profile.py resnet50 512 > "$OUT/plan_profile_resnet50_b512.txt" 2>&1
-python3 tools/conv_lab.py --knobs 128:1,64:1,128:0,64:0 > "$OUT/conv_lab_resnet50_layers.txt" 2>&1
+python3 tools/plan_profile.py repvgg_a1 512 > "$OUT/plan_profile_repvgg_a1_b512.txt" 2>&1
+python3 tools/plan_profile.py mobileone_s1 1024 > "$OUT/plan_profile_mobileone_s1_b1024.txt" 2>&1
+python3 "$B" --model repvgg_a1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_line_repvgg_a1.json" 2>> "$OUT/bench.err"
+python3 "$B" --model mobileone_s1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_line_mobileone_s1.json" 2>> "$OUT/bench.err"
+# the halo-tile 3x3 kernel (round 3): ablations + per-workgroup clock stamps, and SQ / TCC counters of the kernel alone
+python3 tools/halo_lab.py --cases c1,c2,c3,c4 --generic --stamps > "$OUT/halo_lab_resnet50_3x3.txt" 2>&1
+bash tools/pmc_layer.sh "gpurun_out/prof_$R/pmc_c3_halo" c3 128:5 > /dev/null 2>&1 && cp "$OUT/pmc_c3_halo/summary.json" "$OUT/pmc_conv3x3_256_14.json" || echo "pmc c3 failed"
+bash tools/pmc_layer.sh "gpurun_out/prof_$R/pmc_c4_halo" c4 128:5 > /dev/null 2>&1 && cp "$OUT/pmc_c4_halo/summary.json" "$OUT/pmc_conv3x3_512_7.json" || echo "pmc c4 failed"
+python3 tools/first_batch_probe.py > "$OUT/first_batch_probe.txt" 2>&1
+python3 tools/conv_lab.py --knobs 128:1,64:1,128:0,64:0,128:5,64:5 > "$OUT/conv_lab_resnet50_layers.txt" 2>&1
 python3 tools/chain_lab.py --rows 64 > "$OUT/chain_lab_resnet50_pairs.txt" 2>&1
 python3 tools/chain_trace.py 512 64 56 256 64 > "$OUT/chain_trace_64_256_64_at_56.txt" 2>&1
 python3 tools/chain_trace.py 512 256 14 1024 256 > "$OUT/chain_trace_256_1024_256_at_14.txt" 2>&1
