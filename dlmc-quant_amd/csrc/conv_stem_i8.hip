@@ -740,6 +740,9 @@ extern "C" int dlmcq_conv2d_i8_stem_pool_fused(const void* xpad, const int8_t* w
   const int shift = x_is_unsigned ? 128 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const uint8_t* xs = static_cast<const uint8_t*>(xpad);
+  // the ResNet shape (7 rows, stride 2, 64 channels, codes only): pooling in registers (conv_stem_pool7_i8.hip)
+  if (stem_pool7_applies(Hp, Wp, K, R, S, stride, out, codes) && aligned16(codes) && aligned16(xpad))
+    return stem_pool7_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, Hp, Wp, S, shift, ep, st);
 #define DLMCQ_SP_ARGS dim3((uint32_t)(wgs < 1024 ? wgs : 1024)), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep
   switch ((int)R) {
     case 1: hipLaunchKernelGGL((conv_stem_pool_i8_kernel<1>), DLMCQ_SP_ARGS); break;

@@ -348,6 +348,39 @@ def test_stem_with_the_pool_inside():
             same(c2, wc, f"pooled stem {idx} codes-only")
 
 
+def test_resnet_first_layer_with_the_pool_in_registers():
+    """csrc/conv_stem_pool7_i8.hip (7 filter rows, stride 2, 64 channels, codes only: pooling by DPP and running maxima, never
+    through LDS) against conv_stem_pool_i8_kernel (the same entry point asked for the fp32 output as well stays on the old
+    kernel): the same bytes.  Sizes: 224 (two x tiles of 31 + 25 pooled columns, four bands of 14 pooled rows), 32 (one 8-column
+    tile: a single store instruction), 260 (three x tiles), 8 tap columns, images that do not fill the last workgroup, signed
+    codes, a channel with a negative scale (the pool's order flips), no bias, no ReLU."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    cases = [(3, 224, 224, 7, True, False, True), (5, 32, 32, 7, True, True, False), (2, 64, 260, 7, True, False, True),
+             (1, 48, 40, 8, False, False, True), (7, 36, 28, 7, True, True, True)]
+    for idx, (n, h, w, s, unsigned, negscale, relu) in enumerate(cases):
+        gg = gen(900 + idx)
+        x = torch.randn(n, 3, h, w, generator=gg).to(DEV)
+        s_in = torch.tensor([float(x.abs().max()) / 120], device=DEV)
+        zp = torch.tensor([128.0 if unsigned else 0.0], device=DEV)
+        lo, hi = (0, 255) if unsigned else (-127, 127)
+        wt = (torch.randn(64, 3, 7, s, generator=gg) * 0.1).to(DEV)
+        s_w = wt.abs().amax(dim=(1, 2, 3)) / 127 + 1e-6
+        if negscale:
+            s_w[5] = -s_w[5]
+            s_w[49] = -s_w[49]
+        bias = None if idx == 3 else torch.randn(64, generator=gg).to(DEV)
+        xpad = K.quantize_pad_nhwc4(x, s_in, zp, lo, hi, N.FORM_ZEROPOINT, 3)
+        wq, wsum = K.quantize_weight_stem(wt, s_w, -127, 127)
+        ref = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=2, relu=relu, pool=True)
+        q_s = torch.tensor([float(ref.abs().max()) / 255 * 0.9 + 1e-3], device=DEV)
+        emit = K.EmitCodes(q_s, torch.tensor([7.0], device=DEV), 0, 255, N.FORM_ZEROPOINT)
+        out, old = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=2, relu=relu, emit=emit, pool=True)        # old kernel
+        none, new = K.conv2d_i8_stem(xpad, wq, wsum, bias, s_in, zp, s_w, s, stride=2, relu=relu, emit=emit, pool=True, want_out=False)
+        assert none is None and new.shape == old.shape
+        same(new, old, f"pool-in-registers case {idx}")
+
+
 @pytest.mark.parametrize("dtype", [torch.uint8, torch.int8])
 def test_maxpool_on_codes_equals_quantised_maxpool(dtype):
     import torch.nn.functional as F
