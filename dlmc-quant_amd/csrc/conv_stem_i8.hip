@@ -553,7 +553,8 @@ extern "C" int dlmcq_quantize_pad_nhwc4(const float* x, void* out, const float* 
                                         dlmcq_stream_t stream) {
   if (N < 0 || C < 1 || C > 4 || H < 1 || W < 1 || pad < 0 || lo > hi || lo < -128 || hi > 255 || hi - lo > 255)
     return DLMCQ_EINVAL;
-  if (form < DLMCQ_FORM_EMULATE || form > DLMCQ_FORM_SYMMETRIC) return DLMCQ_EINVAL;
+  ConvEpi q{};                          // the image quantiser, evaluated by EpiQuant (needs a non-null `codes` to resolve)
+  if (!epi_set_form(q, form, lo, hi)) return DLMCQ_EINVAL;      // (DLMCQ_EMIT_SHIFT128: the buffer holds `code - 128`, border included)
   if (N == 0) return DLMCQ_OK;
   if (!x || !out || !scale) return DLMCQ_EINVAL;
   if (!aligned4(out)) return DLMCQ_EALIGN;
@@ -566,14 +567,12 @@ extern "C" int dlmcq_quantize_pad_nhwc4(const float* x, void* out, const float* 
   g.wdiv = make_fastdiv((uint32_t)g.Wp);
   g.hdiv = make_fastdiv((uint32_t)g.Hp);
   const int64_t blocks = (total + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
-  ConvEpi q{};                          // the image quantiser, evaluated by EpiQuant (needs a non-null `codes` to resolve)
   q.codes = static_cast<uint8_t*>(out);
   q.q_scale = scale;
   q.q_zp = zero_point;
   q.q_lo = (float)lo;
   q.q_hi = (float)hi;
   q.q_g = ste_g;
-  q.q_form = form;
   hipLaunchKernelGGL(quantize_pad_nhwc4_kernel, dim3((uint32_t)(blocks < 65536 ? blocks : 65536)), dim3(DLMCQ_BLOCK), 0,
                      reinterpret_cast<hipStream_t>(stream), x, static_cast<uint32_t*>(out), g, q);
   return launch_status();

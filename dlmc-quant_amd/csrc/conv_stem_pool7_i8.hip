@@ -40,6 +40,7 @@ constexpr int P7_RING = 16 * P7_ROWB;
 constexpr int P7_STG = 2048;        // code tile of one pooled row: 32 pixels x 64 bytes
 constexpr int P7_NEG = -(1 << 30);  // "this convolution pixel does not exist": never wins a maximum (sums stay below 2^23)
 
+template <bool XS>      // XS: uint8 codes, re-centred (^ 0x80) on every fragment read; false: the buffer already holds `code - 128` (or int8 codes)
 __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                     const float* __restrict__ bias, const int32_t* __restrict__ wsum,
                                                                     const float* __restrict__ s_in, const float* __restrict__ zp_in,
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
   const int p0 = band * g.rows_per_band;
   const int p1 = p0 + g.rows_per_band < g.PP ? p0 + g.rows_per_band : g.PP;
 
-  const uint32_t xorw = shift ? 0x80808080u : 0u;
+  const uint32_t xorw = XS ? 0x80808080u : 0u;
 
   // ---- window rows by LDS-DMA: group G(p) = image rows 4 p + 5 .. 4 p + 8 (padded coordinates) -> ring slots ((p + 1) & 3) * 4 ..;
   // piece i of a group = (row i / 34, unit i % 34); three wave-instructions, the third with 8 lanes ----
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
       i32x4 o2 = o, e2 = e, v0 = w0, v1 = w1;
       if (r + 1 < 7) fetch(r + 1, o2, e2, v0, v1);
       __builtin_amdgcn_sched_barrier(0);
-      const i32x4 ox = i32x4{(int)(o.x ^ xorw), (int)(o.y ^ xorw), (int)(o.z ^ xorw), (int)(o.w ^ xorw)};
-      const i32x4 ex = i32x4{(int)(e.x ^ xorw), (int)(e.y ^ xorw), (int)(e.z ^ xorw), (int)(e.w ^ xorw)};
+      const i32x4 ox = XS ? i32x4{(int)(o.x ^ xorw), (int)(o.y ^ xorw), (int)(o.z ^ xorw), (int)(o.w ^ xorw)} : o;
+      const i32x4 ex = XS ? i32x4{(int)(e.x ^ xorw), (int)(e.y ^ xorw), (int)(e.z ^ xorw), (int)(e.w ^ xorw)} : e;
       aE[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, ex, aE[0], 0, 0, 0);
       aO[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, ox, aO[0], 0, 0, 0);
       aE[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, ex, aE[1], 0, 0, 0);
@@ -293,8 +294,10 @@ int stem_pool7_launch(const uint8_t* x, const int8_t* w, const float* bias, cons
   g.xtdiv = make_fastdiv((uint32_t)g.xtiles);
   g.bdiv = make_fastdiv((uint32_t)g.bands);
   g.xbytes = N * Hp * Wp * 4;
-  hipLaunchKernelGGL(conv_stem_pool7_i8_kernel, dim3((uint32_t)((tasks + 3) / 4)), dim3(256), 0, st, x, w, bias, wsum, in_scale,
-                     in_zero_point, w_scale, g, shift, ep);
+  if (shift) hipLaunchKernelGGL(conv_stem_pool7_i8_kernel<true>, dim3((uint32_t)((tasks + 3) / 4)), dim3(256), 0, st, x, w, bias, wsum, in_scale,
+                                in_zero_point, w_scale, g, shift, ep);
+  else hipLaunchKernelGGL(conv_stem_pool7_i8_kernel<false>, dim3((uint32_t)((tasks + 3) / 4)), dim3(256), 0, st, x, w, bias, wsum, in_scale,
+                          in_zero_point, w_scale, g, shift, ep);
   return launch_status();
 }
 

@@ -671,21 +671,24 @@ def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_cod
     return out, codes, codes3
 
 
-def quantize_pad_nhwc4(x, scale, zero_point, lo, hi, form, pad, g=0.0):
+def quantize_pad_nhwc4(x, scale, zero_point, lo, hi, form, pad, g=0.0, shift128=False):
     """Image batch (N, C <= 4, H, W) fp32, any memory format -> activation codes in a zero-point-padded NHWC
     buffer, 4 bytes per pixel: uint8/int8 tensor (N, H + 2 pad, W + 2 pad, 4) (a view of a slightly larger
-    allocation: the stem kernel over-reads up to 32 bytes)."""
+    allocation: the stem kernel over-reads up to 32 bytes).  `shift128` (unsigned ranges): the buffer holds int8 `code - 128`
+    (DLMCQ_EMIT_SHIFT128); the first-layer kernels then take it as signed codes with the zero point `zp - 128`."""
     N.require_gpu(x)
     if x.dim() != 4 or x.shape[1] > 4 or x.dtype != torch.float32:
         raise ValueError("quantize_pad_nhwc4 takes an fp32 (N, C <= 4, H, W) tensor")
     n, c, h, w = x.shape
     hp, wp = h + 2 * pad, w + 2 * pad
-    flat = torch.empty(n * hp * wp * 4 + 32, dtype=torch.uint8 if lo >= 0 else torch.int8, device=x.device)
+    if shift128 and not (0 <= lo and hi <= 255):
+        raise ValueError("quantize_pad_nhwc4: shift128 needs an unsigned byte range")
+    flat = torch.empty(n * hp * wp * 4 + 32, dtype=torch.uint8 if lo >= 0 and not shift128 else torch.int8, device=x.device)
     scale = _f32c(scale.detach(), x).reshape(-1)
     zero_point = None if zero_point is None else _f32c(zero_point, x).reshape(-1)
     PROFILE.launch("fq_image", x.numel() * 4 + n * hp * wp * 4, lambda: N.check(N.lib.dlmcq_quantize_pad_nhwc4(
-        N.ptr(x), N.ptr(flat), N.ptr(scale), N.ptr(zero_point), n, c, h, w, *x.stride(), int(pad), int(lo), int(hi), int(form),
-        float(g), N.stream_ptr())))
+        N.ptr(x), N.ptr(flat), N.ptr(scale), N.ptr(zero_point), n, c, h, w, *x.stride(), int(pad), int(lo), int(hi),
+        int(form) | (N.EMIT_SHIFT128 if shift128 else 0), float(g), N.stream_ptr())))
     return flat[:n * hp * wp * 4].view(n, hp, wp, 4)
 
 

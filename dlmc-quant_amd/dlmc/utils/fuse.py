@@ -499,8 +499,11 @@ class StemLayer(_PlanLayer):
         k, _, r, s = lay.weight.shape
         emit = self._emit_for(x.shape[0], k, (x.shape[2] + 2 * pad - r) // st + 1, (x.shape[3] + 2 * pad - s) // st + 1)
         in_kernel = self.pool == (3, 2, 1) and k <= 64 and self.w_off is None      # conv + ReLU + MaxPool2d(3, 2, 1) + quantiser: one kernel
-        xpad = K.quantize_pad_nhwc4(x, act.scale, act.zp, act.lo, act.hi, act.form, pad, g=act.g(numel))
-        res = K.conv2d_i8_stem(xpad, self.wq, self.wsum, lay.bias, self._in_scale(numel), act.zp, self.w_scale, s, stride=st,
+        # an unsigned image quantiser's codes go into the padded buffer re-centred (`code - 128`: what the matrix cores multiply),
+        # so the first-layer kernels need not xor every operand fragment they read; the zero point moves with them
+        shifted = act.lo >= 0
+        xpad = K.quantize_pad_nhwc4(x, act.scale, act.zp, act.lo, act.hi, act.form, pad, g=act.g(numel), shift128=shifted)
+        res = K.conv2d_i8_stem(xpad, self.wq, self.wsum, lay.bias, self._in_scale(numel), self.zp_shift if shifted else act.zp, self.w_scale, s, stride=st,
                                relu=self.relu, emit=emit, want_out=self.want_out, pool=in_kernel, w_offset=self.w_off, channels=self.c)
         out, out_codes = res if emit is not None else (res, None)
         return (out, out_codes) if in_kernel else self._finish(out, out_codes)

@@ -70,7 +70,8 @@ typedef void* dlmcq_stream_t; /* hipStream_t */
  * (each byte ^ 0x80) instead of uint8 `code`.  A consumer then takes them as signed codes (x_is_unsigned = 0) with the
  * zero point `zp - 128`: the same integers reach the matrix cores (they multiply signed bytes, so uint8 codes are
  * re-centred on every operand read otherwise), hence the same results.  Accepted by dlmcq_conv2d_i8_nhwc_fused / _asym /
- * _dual and for the SECOND quantiser of the chain entry points (the first one's codes are read in place by the second GEMM);
+ * _dual, by dlmcq_quantize_pad_nhwc4 (its `form`: the padded image buffer then holds `code - 128`, border included) and for
+ * the SECOND quantiser of the chain entry points (the first one's codes are read in place by the second GEMM);
  * every other entry point returns DLMCQ_EINVAL for it. */
 #define DLMCQ_EMIT_SHIFT128 0x100
 
