@@ -468,16 +468,20 @@ static int chain_launch(ChainArgs& a, int64_t M, int64_t C, int64_t K, int64_t C
   if (tiles >= (1ll << 31)) return DLMCQ_ERANGE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((uint32_t)tiles), block(256);
+  size_t dyn = 0;
+#ifdef DLMCQ_LAB
+  dyn = (g_chain_lab & 128 ? 40960 : 0) + (g_chain_lab & 256 ? 81920 : 0);   // timing only: unused dynamic LDS = fewer workgroups per CU
+#endif
   if (C2 == 0) {
-    if (C == 64 && K2 == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 64>), grid, block, 0, st, a, ep1, ep2);
-    else if (C == 64 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 128>), grid, block, 0, st, a, ep1, ep2);
-    else if (C == 128 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 128>), grid, block, 0, st, a, ep1, ep2);
-    else if (C == 128 && K2 == 256) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 256>), grid, block, 0, st, a, ep1, ep2);
-    else if (C == 256 && K2 == 256) hipLaunchKernelGGL((conv_chain_i8_kernel<256, 256>), grid, block, 0, st, a, ep1, ep2);
+    if (C == 64 && K2 == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 64>), grid, block, dyn, st, a, ep1, ep2);
+    else if (C == 64 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 128>), grid, block, dyn, st, a, ep1, ep2);
+    else if (C == 128 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 128>), grid, block, dyn, st, a, ep1, ep2);
+    else if (C == 128 && K2 == 256) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 256>), grid, block, dyn, st, a, ep1, ep2);
+    else if (C == 256 && K2 == 256) hipLaunchKernelGGL((conv_chain_i8_kernel<256, 256>), grid, block, dyn, st, a, ep1, ep2);
     else return DLMCQ_EINVAL;
   } else {
-    if (C == 64 && C2 == 64 && K2 == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 64, 64>), grid, block, 0, st, a, ep1, ep2);
-    else if (C == 128 && C2 == 256 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 128, 256>), grid, block, 0, st, a, ep1, ep2);
+    if (C == 64 && C2 == 64 && K2 == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 64, 64>), grid, block, dyn, st, a, ep1, ep2);
+    else if (C == 128 && C2 == 256 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 128, 256>), grid, block, dyn, st, a, ep1, ep2);
     else return DLMCQ_EINVAL;
   }
   return launch_status();
