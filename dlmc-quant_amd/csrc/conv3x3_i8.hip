@@ -345,7 +345,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
 
   // ---- epilogue: lane (p = l31, h = hsel), register i of block (jc, jp) = channel n0 + wc * CW + jc * 32 + 16 h + i of row
   // q0 + wp * PW + jp * 32 + p.  Dequantise, quantise for the consumer, stage the code tile, store whole rows. ----
-  __builtin_amdgcn_s_barrier();                   // every wave is done with the operand buffers (the code tile is staged there)
+  asm volatile("s_barrier" ::: "memory");         // every wave is done with the operand buffers (the code tile is staged there)
   const EpiQuant eq(ep, ep.relu != 0);            // code(relu(v)) = max(code(v), code(0))
   int8_t* const stg = lds;
   auto row_addr = [&](int rr, bool& ok) -> uint8_t* {   // tile row -> the pixel's K code bytes (ok = it is a pixel of the batch)

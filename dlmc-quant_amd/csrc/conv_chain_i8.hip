@@ -293,12 +293,13 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 
   auto chunk = [&](int n, auto par_c) {
     constexpr int P = decltype(par_c)::value;
-    // chunk n's requests have landed; the stores of chunk n-1 (younger) stay in flight
-    if (n == 0 || nst == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (nst == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    __builtin_amdgcn_s_barrier();     // everyone's DMA pieces are visible; everyone left GEMM 2 of chunk n-1
+    // chunk n's requests have landed; the stores of chunk n-1 (younger) stay in flight.  Then the barrier: everyone's DMA pieces are
+    // visible; everyone left GEMM 2 of chunk n-1.  Wait and barrier are ONE asm statement with a memory clobber, so no LDS access can
+    // be scheduled between them or moved across the barrier (a bare __builtin_amdgcn_s_barrier() does not touch memory for the compiler)
+    if (n == 0 || nst == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (nst == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else if (nst == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
     CHAIN_STAMP();   // 2 + 3n: chunk n's operands are there
     if constexpr (!DUALH) asm volatile("" : "+v"(res[P][0]), "+v"(res[P][1]), "+v"(res[P][2]), "+v"(res[P][3]));
     if (n + 1 < NC) request(n + 1, std::integral_constant<int, 1 - P>{});
@@ -373,8 +374,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
       CHAIN_FINE(1 + g);
     }
     CHAIN_STAMP();   // 3 + 3n: GEMM 1 + epilogue 1 issued
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();     // the 64 x 64 code tile is complete
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the 64 x 64 code tile is complete
     CHAIN_STAMP();   // 4 + 3n: past the mid-chunk barrier
     if (a.codes)     // stage ends: the tile goes out 64 contiguous bytes per pixel (slot s of row r holds segment s ^ (r >> 2 & 3))
       bstore16i(*reinterpret_cast<const i32x4*>(ctile + drow * 64 + pslot * 16), cvo == CH_BIG ? CH_BIG : cvo + n * 64, r_cod);

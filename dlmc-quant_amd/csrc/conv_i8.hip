@@ -287,15 +287,22 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
     stamp(step, 0);
     // step's own loads must have landed; the younger group stays in flight
     static_assert((PF - 1) * GROUP <= 63, "vmcnt is a 6-bit count");
-    if (step + PF - 1 < nsteps) {                  // PF - 1 younger steps stay in flight
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * GROUP) : "memory");
+    // ... then the barrier: everyone's step-k bytes are in LDS; everyone left multiply(k-1).  Wait and barrier are ONE asm statement
+    // with a memory clobber (a bare __builtin_amdgcn_s_barrier() is no memory operation for the compiler: nothing at IR level would
+    // keep an LDS read from moving across it); the stamping lab build keeps them apart to time the wait alone
+    if constexpr (STAMP) {
+      if (step + PF - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * GROUP) : "memory");
+      else if (PF > 2 && step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GROUP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(step, 1);
+      asm volatile("s_barrier" ::: "memory");
+    } else if (step + PF - 1 < nsteps) {           // PF - 1 younger steps stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PF - 1) * GROUP) : "memory");
     } else if (PF > 2 && step + 1 < nsteps) {      // (deeper rings, near the end: at least one younger step)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GROUP) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GROUP) : "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last step
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // last step
     }
-    stamp(step, 1);
-    __builtin_amdgcn_s_barrier();                 // everyone's step-k bytes are in LDS; everyone left multiply(k-1)
     stamp(step, 2);
     if constexpr (SWAP) {
       // the per-channel constants have landed: turn (s_w, SUM qw) into the epilogue's (s_in * s_w, (shift - zp) * SUM qw) in place,
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
   if (STAMP && wgt) wgt[2] = __builtin_readcyclecounter();
   if constexpr (SWAP) {
     // lane (p = l31, h = hsel): register i of block j = channel n0 + 32 j + 16 h + i of pixel m0 + wrow0 + p
-    __builtin_amdgcn_s_barrier();                   // every wave is done with the ring (the code tile is staged there); the
+    asm volatile("s_barrier" ::: "memory");         // every wave is done with the ring (the code tile is staged there); the
                                                     // constants' pre-pass is at least one barrier old
     const EpiQuant eq(ep, ep.relu != 0);            // code(relu(v)) = max(code(v), code(0))
     constexpr int SROW = BN + 16;                   // staged row: BN code bytes + 16 (conflict-free 16-byte accesses)
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
   if ((g.K & 3) == 0) {
     // through LDS: accumulator layout (lane = channel, register = row) -> row-major, so that each lane stores 16 B and
     // each wave-instruction writes 4 rows x 256 contiguous bytes (the 1x1 layers are bound by this output stream).
-    __builtin_amdgcn_s_barrier();                   // every wave is done reading the operand buffers
+    asm volatile("s_barrier" ::: "memory");         // every wave is done reading the operand buffers
     float* stg = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
     static_for<NH>([&](auto h_c) {    // (compile-time indices: the accumulators must stay in registers)
       constexpr int h = decltype(h_c)::value;
