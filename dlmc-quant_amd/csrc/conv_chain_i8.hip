@@ -103,15 +103,21 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   constexpr int WCH = (S1 + S2 + U3) * 4096;  // bytes of one chunk's weights
   constexpr int NPD = DUALH ? 2 : 1;     // constant-table DMAs per wave per chunk
   constexpr int PAR = NPD * 4 * 256;     // per-channel constants of one chunk ((scale, code sum, bias) per pair) x 64 columns
+  // How the accumulator layout (lane = channel, register = row) becomes rows of 4 consecutive channels per lane (TF):
+  //   0  two DPP exchange rounds inside each quad (8 v_mov_dpp + 8 v_cndmask per 4 values).  The quad structure then dictates which
+  //      lane owns which row: 4 adjacent lanes = 4 rows, so a 16-lane group of a shortcut load / output store touches 4 rows x 64 B;
+  //   1  a wave-private 1 KB LDS stage per group of 8 rows (4 ds_write_b32 + 1 ds_read_b128; LDS operations of one wave execute in
+  //      order, so neither a barrier nor a wait separates the writes from the read), same lane -> row mapping as 0: a quarter fewer
+  //      vector instructions and NO gain (round 3: every chain within +-1 %) - the kernel is not bound by their count;
+  //   2  the same stage read back with 8 adjacent lanes = one row's 128 bytes: a 16-lane group of a load / store now touches 2 WHOLE
+  //      128-byte lines.  That is what the fp32 streams respond to (round 2's timing build with 256-byte rows said so): same box, in
+  //      the plan, 56^2 chains -3 .. -7 %, 28^2 -3 .. -5 %, 14^2 -2 %; the 28^2 convolution-shortcut chain (no shortcut loads, LDS
+  //      nearly full) +3 %, so it keeps form 0.  Bit-identical in all forms.
 #ifndef DLMCQ_CHAIN_LDS_T
-#define DLMCQ_CHAIN_LDS_T 0     // (measured in round 3, same box, whole plan: every chain within +-1 % of the DPP form - the kernel is not bound by its vector-instruction count)
+#define DLMCQ_CHAIN_LDS_T ((C1 == 128 && C2 == 256) ? 0 : 2)
 #endif
-  // LDST: the accumulator layout (lane = channel, register = row) is turned into rows of 4 consecutive channels per lane through a
-  // wave-private 1 KB LDS stage per group of 8 rows (4 ds_write_b32 + 1 ds_read_b128, conflict-free with the XOR swizzle below; LDS
-  // operations of one wave execute in order, so neither a barrier nor a wait separates the writes from the read) instead of two DPP
-  // exchange rounds (8 v_mov_dpp + 8 v_cndmask per 4 values: a quarter of the epilogue's vector instructions, which are what
-  // bounds the chains that are not HBM-bound)
-  constexpr bool LDST = DLMCQ_CHAIN_LDS_T != 0;
+  constexpr int TF = DLMCQ_CHAIN_LDS_T;
+  constexpr bool LDST = TF != 0;
   __shared__ __attribute__((aligned(1024))) int8_t lds[2 * WCH + 2 * PAR + 4096 + 3 * KB * 4 + (LDST ? 4096 : 0)];
   int8_t* const par0 = lds + 2 * WCH;
   int8_t* const ctile = lds + 2 * WCH + 2 * PAR;
@@ -120,7 +126,10 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
-  const int q4 = l31 >> 2, b4 = l31 & 3;
+  // the lane's place in the row-major (transposed) form of a group of 8 rows x 32 channels: row `rsel`, channels 4 q4 .. 4 q4 + 3
+  constexpr bool LDST2 = TF == 2;
+  const int q4 = LDST2 ? (lane & 7) : (l31 >> 2), b4 = l31 & 3;
+  const int rsel = LDST2 ? (lane >> 3) : (4 * hsel + b4);
   const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
   const int64_t row0 = (int64_t)blockIdx.x * a.rows_per_tile;
   const int rows_here = (int)((a.M - row0) < a.rows_per_tile ? (a.M - row0) : a.rows_per_tile);
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   int fo[4];     // byte offset of this lane's 16 bytes in chunk 0, per group (CH_BIG: row not in the tile)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const int lr = wr * 32 + 8 * g + 4 * hsel + b4;
+    const int lr = wr * 32 + 8 * g + rsel;
     fo[g] = lr < rows_here ? (int)(((row0 + lr) * a.KD + wc * 32 + q4 * 4) * 4) : CH_BIG;
 #ifdef DLMCQ_LAB
     if (a.lab & 4) {   // timing only: the access pattern a 16 x 16 x 64 accumulator layout would have - 16 rows x 64 bytes per instruction
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     cstep = 64 * 256;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int lr = wr * 32 + 8 * g + 4 * hsel + b4;
+      const int lr = wr * 32 + 8 * g + rsel;
       fo[g] = lr < rows_here ? (int)(row0 * a.KD * 4 + lr * 256 + (wc * 32 + q4 * 4) * 4) : CH_BIG;
     }
   }
@@ -216,8 +225,8 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   // 4 hsel + b4, columns 4 q4 .. + 3; 4-column slot c of row r sits at slot c ^ (r & 7)
   int tw[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) tw[j] = (4 * hsel + j) * 32 + ((l31 & 3) | ((l31 & ~3) ^ ((4 * hsel + j) * 4)));
-  const int trd = (4 * hsel + b4) * 32 + ((4 * q4) ^ ((4 * hsel + b4) * 4));
+  for (int j = 0; j < 4; ++j) tw[j] = (4 * hsel + j) * 32 + (LDST2 ? l31 : ((l31 & 3) | ((l31 & ~3) ^ ((4 * hsel + j) * 4))));
+  const int trd = LDST2 ? rsel * 32 + 4 * q4 : (4 * hsel + b4) * 32 + ((4 * q4) ^ ((4 * hsel + b4) * 4));   // (form 2: 8 lanes read one row = all 32 banks: no swizzle needed)
   const int nst = (a.out ? 4 : 0) + (a.codes ? 1 : 0);   // stores per wave per chunk
 
   // ---- DMA sources.  A wave-instruction lands 16 rows x 64 B; row r of a unit keeps its 16-byte segments XOR-swizzled ----
@@ -270,7 +279,12 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 #ifdef DLMCQ_LAB
       if (a.lab & 1) continue;
 #endif
-      bload16(res[P][g], fo[g] + n * cstep, r_res);
+      int lo = fo[g] + n * cstep;
+#ifdef DLMCQ_LAB
+      if ((a.lab & 512) && fo[g] != CH_BIG) lo -= (int)(row0 * a.KD * 4);   // timing only: every workgroup reads tile 0's rows (L2 hits)
+      if ((a.lab & 2048) && fo[g] != CH_BIG) lo = fo[g] - (int)(row0 * a.KD * 4) + (int)(blockIdx.x & 255u) * (64 * 256) + n * 256 * 0;   // timing only: one private 16 KB region per CU-ish slot, re-read every chunk
+#endif
+      bload16(res[P][g], lo, r_res);
     }
   };
 
@@ -366,10 +380,13 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
       }
       if constexpr (!DUALH) y = y + res[P][g];
       if (ep1.relu) y = relu4_nan(y);
-      const int off = fo[g] + n * cstep;
+      int off = fo[g] + n * cstep;
+#ifdef DLMCQ_LAB
+      if ((a.lab & 1024) && fo[g] != CH_BIG) off -= (int)(row0 * a.KD * 4);      // timing only: every workgroup writes tile 0's rows
+#endif
       if (a.out) bstore16(y, off, r_out);
       const uint32_t c = eq1.code4(y);
-      const int R = wr * 32 + 8 * g + 4 * hsel + b4;
+      const int R = wr * 32 + 8 * g + rsel;
       *reinterpret_cast<uint32_t*>(ctile + R * 64 + (((wc * 2 + (q4 >> 2)) ^ ((R >> 2) & 3)) << 4) + (q4 & 3) * 4) = c;
       CHAIN_FINE(1 + g);
     }
