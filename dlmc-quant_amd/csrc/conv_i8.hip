@@ -455,6 +455,16 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
     // each wave-instruction writes 4 rows x 256 contiguous bytes (the 1x1 layers are bound by this output stream).
     asm volatile("s_barrier" ::: "memory");         // every wave is done reading the operand buffers
     float* stg = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
+    // codes: 4-byte stores straight from this loop (4 rows x 64 B per instruction) cost the dual kernel 16 % of its time; the words
+    // wait in registers instead, go through the (then free) stage once and leave as whole 16-byte pieces of whole rows
+    // (not where 16 more registers would spill: the 128-wide single-pair kernels compiled for four workgroups per CU)
+    constexpr bool WIDE_OK = NH == 1 || DUAL || ASYM || !ADIR;
+    const bool wide_codes = WIDE_OK && ep.codes && (g.K & 15) == 0 && (reinterpret_cast<uintptr_t>(ep.codes) & 15) == 0;
+    uint32_t cw[NH][8];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) cw[h][it] = 0u;
     static_for<NH>([&](auto h_c) {    // (compile-time indices: the accumulators must stay in registers)
       constexpr int h = decltype(h_c)::value;
       // the shortcut tile's latency hides behind the dequantise-and-stage phase below (64-wide tiles: already here)
@@ -485,11 +495,35 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
           if (ep.residual) v = f32x4{v.x + idt[it].x, v.y + idt[it].y, v.z + idt[it].z, v.w + idt[it].w};
           if (ep.relu) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
           if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
-          if (ep.codes) __builtin_nontemporal_store(eq.code4(v), reinterpret_cast<uint32_t*>(ep.codes + at));
+          if (ep.codes) {
+            const uint32_t c = eq.code4(v);
+            if (wide_codes) cw[h][it] = c;
+            else __builtin_nontemporal_store(c, reinterpret_cast<uint32_t*>(ep.codes + at));
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the stage
     });
+    if (wide_codes) {
+      constexpr int CROW = BN + 16;                 // staged code row: BN bytes + 16 (the wave's 32 rows fit its fp32 stage: 32 * CROW <= 32 * EP_LD * 4)
+      static_assert(CROW <= EP_LD * 4, "the code rows are staged where the fp32 rows were");
+      int8_t* cst = reinterpret_cast<int8_t*>(stg);
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+          *reinterpret_cast<uint32_t*>(cst + (it * 4 + er) * CROW + h * 64 + ec) = cw[h][it];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int LPR = BN / 16;                  // lanes per staged row
+      const int srow = lane / LPR, sseg = lane % LPR;
+#pragma unroll
+      for (int it = 0; it < 32 / (64 / LPR); ++it) {
+        const int r = it * (64 / LPR) + srow;
+        const int64_t row = m0 + wrow0 + r;
+        const i32x4 c16 = *reinterpret_cast<const i32x4*>(cst + r * CROW + sseg * 16);
+        if (row < g.M && n0 + sseg * 16 < g.K) __builtin_nontemporal_store(c16, reinterpret_cast<i32x4*>(ep.codes + row * g.K + n0 + sseg * 16));
+      }
+    }
     if (STAMP && wgt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wgt[3] = __builtin_readcyclecounter();
@@ -801,6 +835,33 @@ extern "C" int dlmcq_x_conv2d_i8_trace(const void* x, const int8_t* w, float* ou
   hipLaunchKernelGGL((conv_i8_mfma_kernel<128, false, true, false, 1>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const int8_t*>(x), w, out, bias, wsum, in_scale,
                      in_zero_point, w_scale, g, x_is_unsigned ? 128 : 0, ep, ConvSeg2{});
+  return launch_status();
+}
+
+// the same stamps for the dual kernel (a block's last 1x1 convolution + the 1x1 / stride-s convolution on its shortcut; fp32 out + codes)
+extern "C" int dlmcq_x_conv2d_i8_dual_trace(const void* x, const int8_t* w, const int32_t* wsum, const float* w_scale, const void* x2,
+                                            const int8_t* w2, const int32_t* wsum2, const float* w_scale2, const float* in_scale,
+                                            const float* in_zero_point, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
+                                            int64_t H2, int64_t W2, int64_t C2, int32_t stride2, float* out, void* codes,
+                                            const float* q_scale, dlmcq_stream_t stream, void* trace) {
+  ConvSeg2 s2{};
+  const int rc = make_seg2(s2, N, K, x2, w2, nullptr, wsum2, in_scale, in_zero_point, w_scale2, H2, W2, C2, 1, 1, stride2, 0, 1, 1);
+  if (rc != DLMCQ_OK) return rc;
+  ConvEpi ep = make_epi(static_cast<const float*>(trace), 1, codes, q_scale, nullptr, 0, 255, DLMCQ_FORM_ZEROPOINT, 0.0f);
+  if (C % CV_BK || C2 % CV_BK || K % 128) return DLMCQ_EINVAL;
+  ConvGeom g;
+  g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C = (int)C; g.K = (int)K; g.R = 1; g.S = 1;
+  g.stride = 1; g.pad = 0; g.dil = 1; g.P = (int)H; g.Q = (int)W; g.M = N * H * W;
+  g.qdiv = make_fastdiv((uint32_t)W);
+  g.pdiv = make_fastdiv((uint32_t)H);
+  g.nblk_m = (int)((g.M + CV_BM - 1) / CV_BM);
+  g.nblk_n = (int)(K / 128);
+  s2.g.nblk_m = g.nblk_m;
+  s2.g.nblk_n = g.nblk_n;
+  if (s2.g.M != g.M) return DLMCQ_EINVAL;
+  hipLaunchKernelGGL((conv_i8_mfma_kernel<128, true, true, false, 1>), dim3((uint32_t)((int64_t)g.nblk_m * g.nblk_n)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const int8_t*>(x), w, out, nullptr, wsum, in_scale,
+                     in_zero_point, w_scale, g, 128, ep, s2);
   return launch_status();
 }
 
