@@ -279,11 +279,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 #ifdef DLMCQ_LAB
       if (a.lab & 1) continue;
 #endif
-      int lo = fo[g] + n * cstep;
-#ifdef DLMCQ_LAB
-      if ((a.lab & 512) && fo[g] != CH_BIG) lo -= (int)(row0 * a.KD * 4);   // timing only: every workgroup reads tile 0's rows (L2 hits)
-      if ((a.lab & 2048) && fo[g] != CH_BIG) lo = fo[g] - (int)(row0 * a.KD * 4) + (int)(blockIdx.x & 255u) * (64 * 256) + n * 256 * 0;   // timing only: one private 16 KB region per CU-ish slot, re-read every chunk
-#endif
+      const int lo = fo[g] + n * cstep;
       bload16(res[P][g], lo, r_res);
     }
   };
@@ -380,10 +376,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
       }
       if constexpr (!DUALH) y = y + res[P][g];
       if (ep1.relu) y = relu4_nan(y);
-      int off = fo[g] + n * cstep;
-#ifdef DLMCQ_LAB
-      if ((a.lab & 1024) && fo[g] != CH_BIG) off -= (int)(row0 * a.KD * 4);      // timing only: every workgroup writes tile 0's rows
-#endif
+      const int off = fo[g] + n * cstep;
       if (a.out) bstore16(y, off, r_out);
       const uint32_t c = eq1.code4(y);
       const int R = wr * 32 + 8 * g + rsel;
