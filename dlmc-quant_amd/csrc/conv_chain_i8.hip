@@ -52,6 +52,7 @@ struct ChainArgs {
   const int32_t* wsum3;
   const float* bias3;
   uint8_t* codes2;         // [M][KB]
+  int w3_row, w3_chunk;    // byte strides of w3: from output channel to output channel, from 64-column chunk to chunk (KRSC: KD, 64; chunk-major: 64, KB * 64)
   int M, KD, rows_per_tile;
   int lab;                     // lab builds: 1 = no shortcut loads (timing only)
   unsigned long long* trace;   // lab builds: 64 clock-stamp slots per workgroup (null: none)
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   // 16 hsel + i of its 32-channel block: LDS row d of a block holds channel 16 ((d >> 2) & 1) + 4 (d >> 3) + (d & 3)
   const int d3 = drow & 31;
   const int prow3 = (drow & 32) + 16 * ((d3 >> 2) & 1) + 4 * (d3 >> 3) + (d3 & 3);
-  const int8_t* w3p = a.w3 + (int64_t)prow3 * a.KD + dseg;  // + unit * 64 * KD + chunk * 64
+  const int8_t* w3p = a.w3 + (int64_t)prow3 * a.w3_row + dseg;  // + unit * 64 * w3_row + chunk * w3_chunk
   const int cvo = drow < rows_here ? (int)((row0 + drow) * a.KD + dseg) : CH_BIG;   // this lane's 16 bytes of the code tile, chunk 0
   const void* const pars[4] = {a.s_w1, a.wsum1, a.bias1 ? (const void*)a.bias1 : (const void*)a.s_w1, a.s_w1};
   const int32_t* parp = static_cast<const int32_t*>(wave == 0 ? pars[0] : wave == 1 ? pars[1] : wave == 2 ? pars[2] : pars[3]) + lane;
@@ -262,10 +263,19 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 #endif
 #pragma unroll
     for (int s = 0; s < S1; ++s)
-      if (wdma) __builtin_amdgcn_global_load_lds((gptr_t)(w1p + (int64_t)n * 64 * C1 + s * 64), (lptr_t)(wb + s * 4096 + wave * 1024), 16, 0, 0);
+      if (wdma) {
+        const int8_t* src = w1p + (int64_t)n * 64 * C1 + s * 64;
+#ifdef DLMCQ_LAB
+        if (a.lab & 512) src = a.w1 + (int64_t)n * 64 * C1 + (s * 4 + wave) * 1024 + lane * 16;   // timing only: 1 KB contiguous per instruction (what a whole-row LDS layout of W1 would read)
+#endif
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wb + s * 4096 + wave * 1024), 16, 0, 0);
+      }
 #pragma unroll
     for (int u = 0; u < U3; ++u)
-      if (wdma) __builtin_amdgcn_global_load_lds((gptr_t)(w3p + (int64_t)u * 64 * a.KD + n * 64), (lptr_t)(wb + (S1 + S2 + u) * 4096 + wave * 1024), 16, 0, 0);
+      if (wdma) {
+        const int8_t* src = w3p + (int64_t)u * 64 * a.w3_row + (int64_t)n * a.w3_chunk;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wb + (S1 + S2 + u) * 4096 + wave * 1024), 16, 0, 0);
+      }
     __builtin_amdgcn_global_load_lds((gptr_t)(parp + n * 64), (lptr_t)(par0 + P * PAR + wave * 256), 4, 0, 0);
     if constexpr (DUALH) {
 #pragma unroll
@@ -458,6 +468,10 @@ static int chain_launch(ChainArgs& a, int64_t M, int64_t C, int64_t K, int64_t C
                         int32_t relu2, void* codes2, const float* q2_scale, const float* q2_zero_point, int32_t q2_lo, int32_t q2_hi,
                         int32_t q2_form, float q2_ste_g, int32_t rows_per_tile, dlmcq_stream_t stream) {
   if (q_lo != 0 || q_hi != 255) return DLMCQ_EINVAL;   // GEMM 2 reads the codes as uint8 (shift 128)
+  const bool w3cm = (q2_form & DLMCQ_W2_CHUNK_MAJOR) != 0;
+  q2_form &= ~DLMCQ_W2_CHUNK_MAJOR;
+  a.w3_row = w3cm ? 64 : (int)K;
+  a.w3_chunk = w3cm ? (int)K2 * 64 : 64;
   ConvEpi ep1{}, ep2{};
   if (q2_lo > q2_hi || q2_lo < -128 || q2_hi > 255 || q2_hi - q2_lo > 255 || q_form < DLMCQ_FORM_EMULATE ||
       q_form > DLMCQ_FORM_SYMMETRIC || !epi_set_form(ep2, q2_form, q2_lo, q2_hi))

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("DLMCQ_LIBRARY") or os.path.join(os.path.dirname(_HERE
 # enums of include/dlmcq.h
 FORM_EMULATE, FORM_QBASE, FORM_ZEROPOINT, FORM_SYMMETRIC, FORM_ROOTQ_ACT = range(5)
 EMIT_SHIFT128 = 0x100    # DLMCQ_EMIT_SHIFT128: OR-able into q_form (include/dlmcq.h)
+W2_CHUNK_MAJOR = 0x200   # DLMCQ_W2_CHUNK_MAJOR: OR-able into the chain entry points' last quantiser form
 Y_DEQUANT, Y_CODES = 0, 1
 CODES_NONE, CODES_I8, CODES_P4 = 0, 1, 2
 MINMAX_ABSMAX, MINMAX_MINMAX, MINMAX_NEGMIN = 0, 1, 2

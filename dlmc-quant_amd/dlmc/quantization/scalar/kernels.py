@@ -566,6 +566,26 @@ def chain_supported(c, k, k2, m):
     return (c, k2) in CHAIN_SHAPES and k % 64 == 0 and m * k * 4 <= 0x7fff0000
 
 
+def chunk_major(wq):
+    """Weight codes [K2, 1, 1, K] (KRSC) of a 1x1 layer -> [K / 64, K2, 64]: the layout the chain kernels take for their second layer
+    under DLMCQ_W2_CHUNK_MAJOR (a chunk of 64 input columns = one contiguous K2 x 64 byte block)."""
+    k2, r, s_, k = wq.shape
+    if (r, s_) != (1, 1) or k % 64:
+        raise ValueError("chunk_major: a 1x1 layer with K % 64 = 0")
+    return wq.reshape(k2, k // 64, 64).permute(1, 0, 2).contiguous()
+
+
+def _second_weights(b):
+    """(pointer tensor, form flag) of a chain kernel's second layer: its chunk-major copy when the operand dict carries one."""
+    wc = b.get("wq_chunk")
+    if wc is None:
+        return b["wq"], 0
+    k2, _, _, k = b["wq"].shape
+    if tuple(wc.shape) != (k // 64, k2, 64) or wc.dtype != torch.int8 or not wc.is_contiguous():
+        raise ValueError("wq_chunk must be chunk_major(wq)")
+    return wc, N.W2_CHUNK_MAJOR
+
+
 def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_codes=False, relu2=True, emit2=None,
                     rows_per_tile=0):
     """A block's last 1x1 convolution (+ residual, ReLU, the consumer's quantiser `emit`) and the next block's first 1x1
@@ -605,11 +625,12 @@ def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_co
     qs, qz = _f32c(emit.scale.detach(), c).reshape(-1), None if emit.zero_point is None else _f32c(emit.zero_point, c).reshape(-1)
     qs2, qz2 = _f32c(emit2.scale.detach(), c).reshape(-1), None if emit2.zero_point is None else _f32c(emit2.zero_point, c).reshape(-1)
     nbytes = c.numel() + a["wq"].numel() + b["wq"].numel() + m * K_ * (4 + 4 * want_out + want_codes) + m * K2
+    w2t, w2flag = _second_weights(b)
     PROFILE.launch("conv_chain", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_chain(
         N.ptr(c), N.ptr(a["wq"]), N.ptr(out), N.ptr(b1), N.ptr(a["wsum"]), N.ptr(si), N.ptr(zp), N.ptr(ws1), m, ch, K_,
         int(c.dtype == torch.uint8), N.ptr(residual), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi,
-        emit.form, emit.g, N.ptr(b["wq"]), N.ptr(b2), N.ptr(b["wsum"]), N.ptr(ws2), K2, int(bool(relu2)), N.ptr(codes2),
-        N.ptr(qs2), N.ptr(qz2), emit2.lo, emit2.hi, emit2.form_arg, emit2.g, int(rows_per_tile), N.stream_ptr())))
+        emit.form, emit.g, N.ptr(w2t), N.ptr(b2), N.ptr(b["wsum"]), N.ptr(ws2), K2, int(bool(relu2)), N.ptr(codes2),
+        N.ptr(qs2), N.ptr(qz2), emit2.lo, emit2.hi, emit2.form_arg | w2flag, emit2.g, int(rows_per_tile), N.stream_ptr())))
     return out, codes, codes2
 
 
@@ -662,12 +683,13 @@ def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_cod
     m = n * h * w_
     nbytes = ca.numel() + cb.numel() // (st2 * st2) + a["wq"].numel() + b["wq"].numel() + c3["wq"].numel() + \
         m * K_ * (4 * want_out + want_codes) + m * K3
+    w3t, w3flag = _second_weights(c3)
     PROFILE.launch("conv_chain", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_dual_chain(
         N.ptr(ca), N.ptr(a["wq"]), N.ptr(out), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa), n, h, w_, ch, K_,
         int(ca.dtype == torch.uint8), N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2,
         ch2, st2, int(cb.dtype == torch.uint8), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi, emit.form, emit.g,
-        N.ptr(c3["wq"]), N.ptr(b3), N.ptr(c3["wsum"]), N.ptr(ws3), K3, int(bool(relu3)), N.ptr(codes3), N.ptr(qs3), N.ptr(qz3), emit3.lo,
-        emit3.hi, emit3.form_arg, emit3.g, int(rows_per_tile), N.stream_ptr())))
+        N.ptr(w3t), N.ptr(b3), N.ptr(c3["wsum"]), N.ptr(ws3), K3, int(bool(relu3)), N.ptr(codes3), N.ptr(qs3), N.ptr(qz3), emit3.lo,
+        emit3.hi, emit3.form_arg | w3flag, emit3.g, int(rows_per_tile), N.stream_ptr())))
     return out, codes, codes3
 
 

@@ -381,6 +381,7 @@ class ChainInt8Layer(nn.Module):
         # strided operand of the sum (fp32 addition commutes: which of the two the dual plan node called `a` does not matter)
         self.a, self.b, self.want_codes, self.short, self.main = a, b, bool(want_codes), short, (main if main is not None else a)
         self.swapped = short is not None and self.main is not a       # main reads the plan node's SECOND input
+        self._w2cm = None      # the second layer's weight codes chunk-major (K.chunk_major), made at the first forward
 
     def forward(self, x, y):
         a, b, sc, mn = self.a, self.b, self.short, self.main
@@ -389,6 +390,10 @@ class ChainInt8Layer(nn.Module):
         codes = mn._codes(x)
         n, c, h, w = codes.shape
         nxt = dict(wq=b.wq, wsum=b.wsum, bias=b._bias(), w_scale=b.w_scale)
+        if not getattr(b, "_packed4", False):     # (4-bit weights live packed and are expanded per forward: they stay KRSC)
+            if self._w2cm is None or self._w2cm.device != b.wq.device:
+                self._w2cm = K.chunk_major(b.wq)  # the plan's weights are frozen: made once
+            nxt["wq_chunk"] = self._w2cm
         kw = dict(relu=a.relu, emit=a._emit_for(n, a.k, h, w), want_out=a.want_out, want_codes=self.want_codes, emit2=b._emit_for(n, b.k, h, w))
         if sc is None:
             if not K.chain_supported(c, a.k, b.k, n * h * w):
@@ -592,6 +597,7 @@ class PackedWeights4(nn.Module):
         self.n = total
         for n, o, sz in zip(nodes, offs, sizes):              # the nodes keep no copy of their own: `wq` becomes a view of the scratch
             n._buffers["wq"] = self.scratch[o:o + sz].view(n.wq.shape)
+            n._packed4 = True
         self.expand()
 
     def expand(self):

@@ -74,6 +74,11 @@ typedef void* dlmcq_stream_t; /* hipStream_t */
  * the SECOND quantiser of the chain entry points (the first one's codes are read in place by the second GEMM);
  * every other entry point returns DLMCQ_EINVAL for it. */
 #define DLMCQ_EMIT_SHIFT128 0x100
+/* OR-able into the LAST quantiser form argument of the chain entry points (`q2_form` of dlmcq_conv2d_i8_nhwc_chain, `q3_form` of
+ * dlmcq_conv2d_i8_nhwc_dual_chain): the second 1x1 layer's weight codes are handed over CHUNK-MAJOR, int8 [K / 64][K2][64]
+ * (element [n][k2][j] = KRSC element [k2][64 n + j]), so that the 64-column chunk the kernel stages per step is one contiguous
+ * K2 x 64 byte block (whole cache lines per LDS-DMA instruction instead of 64-byte pieces of K-byte rows).  Same results. */
+#define DLMCQ_W2_CHUNK_MAJOR 0x200
 
 /* ---- what is written to `y` ---- */
 #define DLMCQ_Y_DEQUANT 0 /* the fake-quantised value y */

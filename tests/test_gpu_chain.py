@@ -48,6 +48,11 @@ def test_chain_matches_two_calls(c, k, k2, rows):
         if want_codes:
             assert torch.equal(codes, codes_r)
         assert torch.equal(codes2, codes2_r)
+    # the second layer's weights handed over chunk-major (DLMCQ_W2_CHUNK_MAJOR): same bytes out
+    bc = dict(b, wq_chunk=K.chunk_major(b["wq"]))
+    out, codes, codes2 = K.conv2d_i8_chain(a, bc, res, relu=True, emit=emit, want_out=True, want_codes=True, relu2=True, emit2=emit2,
+                                           rows_per_tile=rows)
+    assert torch.equal(out.view(torch.int32), out_r.view(torch.int32)) and torch.equal(codes, codes_r) and torch.equal(codes2, codes2_r)
 
 
 def test_chain_larger_batch_and_nonzero_zero_points():
@@ -93,6 +98,9 @@ def test_dual_chain_matches_dual_plus_fused(c, c2, k, k3, stride):
         if want_codes:
             assert torch.equal(codes, codes_r)
         assert torch.equal(codes3, codes3_r)
+    c3c = dict(c3, wq_chunk=K.chunk_major(c3["wq"]))     # DLMCQ_W2_CHUNK_MAJOR on the third layer
+    out, codes, codes3 = K.conv2d_i8_dual_chain(a, b, c3c, relu=True, emit=emit, want_out=True, want_codes=True, relu3=True, emit3=emit3)
+    assert torch.equal(out.view(torch.int32), out_r.view(torch.int32)) and torch.equal(codes, codes_r) and torch.equal(codes3, codes3_r)
 
 
 def test_chain_refuses_unsupported_shapes():
