@@ -146,35 +146,27 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 #endif
   CHAIN_STAMP();   // 0: start
 
-  // ---- A fragments of the whole tile row block (rows beyond the tile read its last row: never stored) ----
-  i32x4 af[S1][2];
+  // ---- The tile's input rows (rows beyond the tile read its last row: never stored) go to LDS by LDS-DMA, 16 rows x 64 B per
+  // wave-instruction, into buffer 1 of the weight double buffer - in W1's (W2's) own unit layout and swizzle, so the fragment
+  // reads below are GEMM 1's weight-fragment reads with another base.  (Round 3: the fragments used to be loaded straight into
+  // registers, 16 bytes per lane from 32 different rows per instruction - the costliest shape a vector-memory instruction
+  // can have here - and twice over, once per column wave; in the short chains that was a quarter of a tile's requests.) ----
   {
-    const int lr = wr * 32 + l31;
-    const int8_t* xp = a.x + (row0 + (lr < rows_here ? lr : rows_here - 1)) * C1 + hsel * 16;
-    const uint32_t xw = a.shift1 ? 0x80808080u : 0u;
+    const int lrw = tid >> 2;                                 // = wave * 16 + (lane >> 2): the row of a 64-row unit this lane fetches
+    const int sgw = ((tid & 3) ^ ((lrw >> 2) & 3)) * 16;
+    const int8_t* xp = a.x + (row0 + (lrw < rows_here ? lrw : rows_here - 1)) * C1 + sgw;
 #pragma unroll
     for (int s = 0; s < S1; ++s)
+      __builtin_amdgcn_global_load_lds((gptr_t)(xp + s * 64), (lptr_t)(lds + WCH + s * 4096 + (tid >> 6) * 1024), 16, 0, 0);
+    if constexpr (DUALH) {
+      const uint32_t m = (uint32_t)(row0 + (lrw < rows_here ? lrw : rows_here - 1));
+      const uint32_t t = fdiv(m, a.qdiv), nn = fdiv(t, a.pdiv);
+      const int q = (int)(m - t * (uint32_t)a.Q), pp = (int)(t - nn * (uint32_t)a.P);
+      const int8_t* xp2 = a.x2 + (((int64_t)nn * a.H2 + pp * a.stride2) * a.W2 + q * a.stride2) * C2 + sgw;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const i32x4 t = *reinterpret_cast<const i32x4*>(xp + s * 64 + ks * 32);
-        af[s][ks] = i32x4{(int)(t.x ^ xw), (int)(t.y ^ xw), (int)(t.z ^ xw), (int)(t.w ^ xw)};
-      }
-  }
-  i32x4 af2[DUALH ? S2 : 1][2];
-  if constexpr (DUALH) {
-    const int lr = wr * 32 + l31;
-    const uint32_t m = (uint32_t)(row0 + (lr < rows_here ? lr : rows_here - 1));
-    const uint32_t t = fdiv(m, a.qdiv), nn = fdiv(t, a.pdiv);
-    const int q = (int)(m - t * (uint32_t)a.Q), pp = (int)(t - nn * (uint32_t)a.P);
-    const int8_t* xp = a.x2 + (((int64_t)nn * a.H2 + pp * a.stride2) * a.W2 + q * a.stride2) * C2 + hsel * 16;
-    const uint32_t xw = a.shift2 ? 0x80808080u : 0u;
-#pragma unroll
-    for (int s = 0; s < S2; ++s)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const i32x4 t4 = *reinterpret_cast<const i32x4*>(xp + s * 64 + ks * 32);
-        af2[s][ks] = i32x4{(int)(t4.x ^ xw), (int)(t4.y ^ xw), (int)(t4.z ^ xw), (int)(t4.w ^ xw)};
-      }
+      for (int s = 0; s < S2; ++s)
+        __builtin_amdgcn_global_load_lds((gptr_t)(xp2 + s * 64), (lptr_t)(lds + WCH + (S1 + s) * 4096 + (tid >> 6) * 1024), 16, 0, 0);
+    }
   }
   // GEMM 2's epilogue constants, once per workgroup (its accumulator is kept with the operands swapped - weights as A, the
   // code tile as B - so a lane owns 16 consecutive channels of one pixel and reads their constants as broadcast ds_read_b128)
@@ -186,8 +178,34 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     reinterpret_cast<int*>(par3)[KB + tid] = dz2 * a.wsum3[tid];
     reinterpret_cast<float*>(par3)[2 * KB + tid] = a.bias3 ? a.bias3[tid] : 0.0f;
   }
-  // make sure no compiler-known load is outstanding from here on (the counted waits below assume it)
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // the input tile has landed, and no compiler-known load is outstanding from here on (the counted waits below assume it)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  i32x4 af[S1][2];
+  i32x4 af2[DUALH ? S2 : 1][2];
+  {
+    const int r = wr * 32 + l31;
+    const int8_t* ab = lds + WCH + r * 64;
+    const uint32_t xw = a.shift1 ? 0x80808080u : 0u;
+#pragma unroll
+    for (int s = 0; s < S1; ++s)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const i32x4 t = *reinterpret_cast<const i32x4*>(ab + s * 4096 + (((ks * 2 + hsel) ^ ((r >> 2) & 3)) << 4));
+        af[s][ks] = i32x4{(int)(t.x ^ xw), (int)(t.y ^ xw), (int)(t.z ^ xw), (int)(t.w ^ xw)};
+      }
+    if constexpr (DUALH) {
+      const uint32_t xw2 = a.shift2 ? 0x80808080u : 0u;
+#pragma unroll
+      for (int s = 0; s < S2; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const i32x4 t = *reinterpret_cast<const i32x4*>(ab + (S1 + s) * 4096 + (((ks * 2 + hsel) ^ ((r >> 2) & 3)) << 4));
+          af2[s][ks] = i32x4{(int)(t.x ^ xw2), (int)(t.y ^ xw2), (int)(t.z ^ xw2), (int)(t.w ^ xw2)};
+        }
+    }
+  }
+  // (the fragments are in registers before this wave reaches chunk 0's barrier, behind which buffer 1 is requested for chunk 1)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   CHAIN_STAMP();   // 1: A fragments in registers
 
   // ---- addressing of the fp32 tile in the transposed (row-major) layout: group g -> row wr*32 + 8g + 4 hsel + b4 ----

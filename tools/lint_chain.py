@@ -37,8 +37,8 @@ def regs(line):
 def in_flight_check(name, body):
     """Registers of the in-loop asm loads must not be touched before the next vmcnt wait.  Returns the number of problems."""
     heads = [i for i, l in enumerate(body) if "=>This Loop Header: Depth=1" in l or ("Loop Header: Depth=1" in l and "=>" in l)]
-    first_bar = next(i for i, l in enumerate(body) if "s_barrier" in l)
-    heads = [h for h in heads if h > first_bar - 200]
+    first_bar = next(i for i, l in enumerate(body) if "s_barrier" in l)     # (the prologue's: the chunk loop starts behind it)
+    heads = [h for h in heads if h > first_bar]
     if not heads:
         print(f"{name}: chunk loop header not found")
         return 1
@@ -98,12 +98,16 @@ def main():
     bad = 0
     for name, body in kernels.items():
         bars = [i for i, l in enumerate(body) if "s_barrier" in l]
-        assert len(bars) >= 4, name
+        assert len(bars) >= 5, name
+        # the chunk loop: from its header to the last barrier (the prologue has one barrier of its own - the input tile staged in LDS -
+        # before any asm load is in flight: a spill there is only reported)
+        heads = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l and "=>" in l and i > bars[0]]
+        lo = heads[0] if heads else bars[1]
         for i, l in enumerate(body):
             if "scratch_" in l:
-                where = "inside the chunk loop" if bars[0] < i < bars[-1] else "outside the loop"
-                print(f"{name}: line {i}: {l.strip()}  [{where}]")
-                bad += bars[0] < i < bars[-1]
+                inside = lo < i < bars[-1]
+                print(f"{name}: line {i}: {l.strip()}  [{'inside the chunk loop' if inside else 'outside the loop'}]")
+                bad += inside
             if "buffer_store_dwordx4" in l:
                 nxt = next(b.strip() for b in body[i + 1:] if b.strip() and not b.strip().startswith(";"))
                 if nxt != "s_nop 1":
