@@ -215,18 +215,27 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
     __syncthreads();
   }
 
-  for (int tile = blockIdx.x * 4 + wave; tile < g.ntiles; tile += gridDim.x * 4) {
-    const int64_t m0 = (int64_t)tile * 32;
-    int64_t m = m0 + (lane & 31);
-    if (m >= g.M) m = g.M - 1;                       // ragged last tile: recompute a valid pixel, never stored
+  // the operand fragments of a tile are requested one tile ahead (before the previous tile's epilogue): a wave's loop is
+  // load -> R MFMAs -> a long quantising epilogue, and without the prefetch every iteration exposed the load's latency
+  auto fetch = [&](int tile, i32x4 (&f)[R]) {
+    int64_t m = (int64_t)tile * 32 + (lane & 31);
+    if (m >= g.M) m = g.M - 1;                       // ragged last tile / beyond the last tile: a valid pixel, never stored
     const uint32_t t = fdiv((uint32_t)m, g.qdiv);
     const int q = (int)((uint32_t)m - t * (uint32_t)g.Q);
     const uint32_t n = fdiv(t, g.pdiv);
     const int p = (int)(t - n * (uint32_t)g.P);
     const uint8_t* src = x + (((int64_t)n * g.Hp + (int64_t)p * g.stride) * g.Wp + (int64_t)q * g.stride) * 4 + hsel * 16;
+#pragma unroll
+    for (int r = 0; r < R; ++r) f[r] = *reinterpret_cast<const i32x4*>(src + (int64_t)r * rowbytes);
+  };
+  i32x4 afn[R];
+  if ((int)(blockIdx.x * 4 + wave) < g.ntiles) fetch(blockIdx.x * 4 + wave, afn);
+  for (int tile = blockIdx.x * 4 + wave; tile < g.ntiles; tile += gridDim.x * 4) {
+    const int64_t m0 = (int64_t)tile * 32;
     i32x4 af[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) af[r] = *reinterpret_cast<const i32x4*>(src + (int64_t)r * rowbytes);
+    for (int r = 0; r < R; ++r) af[r] = afn[r];
+    fetch(tile + (int)gridDim.x * 4, afn);
     i32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
