@@ -281,13 +281,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 #endif
 #pragma unroll
     for (int s = 0; s < S1; ++s)
-      if (wdma) {
-        const int8_t* src = w1p + (int64_t)n * 64 * C1 + s * 64;
-#ifdef DLMCQ_LAB
-        if (a.lab & 512) src = a.w1 + (int64_t)n * 64 * C1 + (s * 4 + wave) * 1024 + lane * 16;   // timing only: 1 KB contiguous per instruction (what a whole-row LDS layout of W1 would read)
-#endif
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wb + s * 4096 + wave * 1024), 16, 0, 0);
-      }
+      if (wdma) __builtin_amdgcn_global_load_lds((gptr_t)(w1p + (int64_t)n * 64 * C1 + s * 64), (lptr_t)(wb + s * 4096 + wave * 1024), 16, 0, 0);
 #pragma unroll
     for (int u = 0; u < U3; ++u)
       if (wdma) {
