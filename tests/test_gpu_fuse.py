@@ -254,6 +254,9 @@ STEM_CASES = [  # N, C, H, W, K, R, S, stride, pad
     (1, 4, 12, 12, 32, 5, 5, 1, 2),
     (2, 1, 9, 9, 8, 1, 1, 1, 0),
     (9, 3, 20, 20, 64, 7, 8, 2, 3),      # 8 taps per row; M = 9*10*9 = 810 (ragged tile)
+    (2, 4, 8, 12, 32, 3, 3, 1, 1),       # four channels through the four-pixels-per-thread image quantiser (NCHW, W % 4 = 0)
+    (2, 1, 8, 8, 8, 1, 1, 1, 0),         # one channel through it
+    (2, 2, 6, 16, 16, 3, 3, 1, 2),       # two channels, pad 2
 ]
 
 
