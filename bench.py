@@ -28,9 +28,10 @@ One JSON line on rank 0.  Besides the contract fields:
                        `traffic` comes from the committed rocprofv3 PMC passes of the same command (`traffic_measured_in_run`
                        says so: counters cannot be read from inside the process)
   roofline_second_kernel  the same for the other int8 kernel (csrc/conv_i8.hip: 3x3s, stage 3 / 4 block ends, first 1x1s, fc)
-  first_batch          one more calibrating forward (every observer re-armed): SURVEY 8(d)'s "first batch, observer on" (module
-                       path: the wrappers' own kernels + torch's ReLU / add between them; the one host read per layer - is the
-                       zero point an integer? - costs 1.7 of its ~30 ms, tools/first_batch_probe.py)
+  first_batch          one more calibrating forward (every observer re-armed): SURVEY 8(d)'s "first batch, observer on", through
+                       dlmc.utils.fuse.EagerFused (layer + shortcut add + ReLU as one int8 launch; same scales); `module_path_ms`
+                       = the same through the wrappers alone (torch's ReLU / add between them; the one host read per layer - is
+                       the zero point an integer? - costs 1.7 of its ~30 ms, tools/first_batch_probe.py)
   roofline_fake_quant  the stand-alone fake-quant kernel, measured live on BASELINE configs[1]'s tensor
   quant_work_8d        SURVEY.md 8(d)'s own accounting of the step: the bytes the reference's fake-quant passes move for this
                        batch (8 B per fake-quantised activation / weight element) over the WHOLE step's time, against 8 TB/s.
@@ -277,15 +278,33 @@ def main():
         if args.conv == "int8":
             # SURVEY 8(d) config 3 also asks for the first batch (observers on): re-arm every wrapper's observer and time ONE
             # more calibrating forward (the first one above also paid the one-time costs: code-object loads, allocator growth)
-            for m in model.modules():
-                if hasattr(m, "_init") and hasattr(m, "in_init_state") and hasattr(m, "wt_init_state"):
-                    m._init.mark(m, "in_init_state", False)
-                    m._init.mark(m, "wt_init_state", False)
+            def rearm():
+                for m in model.modules():
+                    if hasattr(m, "_init") and hasattr(m, "in_init_state") and hasattr(m, "wt_init_state"):
+                        m._init.mark(m, "in_init_state", False)
+                        m._init.mark(m, "wt_init_state", False)
+            rearm()
             barrier()
             t0 = time.perf_counter()
             model(x)
             barrier()
-            first_batch_ms = (time.perf_counter() - t0) * 1e3
+            first_batch_module_ms = (time.perf_counter() - t0) * 1e3
+            # the same calibrating forward with every layer -> (+ shortcut) -> ReLU chain on the int8 route as ONE launch
+            # (dlmc.utils.fuse.EagerFused: the wrappers observe and calibrate as above and end with identical scales - tested)
+            first_batch_ms, first_batch_how = first_batch_module_ms, "module path"
+            try:
+                from dlmc.utils.fuse import EagerFused
+                eager = EagerFused(model)            # reads the dataflow once (torch.fx), as the plan does
+                rearm()
+                eager(x)                             # (one-time costs of this route)
+                rearm()
+                barrier()
+                t0 = time.perf_counter()
+                eager(x)
+                barrier()
+                first_batch_ms, first_batch_how = (time.perf_counter() - t0) * 1e3, "EagerFused"
+            except RuntimeError as e:                # a model torch.fx cannot trace keeps the module path
+                print(f"[bench] EagerFused not used: {e}", file=sys.stderr)
         if args.fused:
             from dlmc.utils.fuse import fuse_inference
             model = fuse_inference(model)        # scales are frozen from here on (BASELINE configs[2]: steady state)
@@ -462,9 +481,12 @@ def main():
                                f"224x224 {'relu(N(0,1))' if args.input == 'halfnormal' else 'N(0,1)'} pixels, batch {args.batch} per GPU, scales frozen",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},
         **({"first_batch": {"ms": round(first_batch_ms, 2), "images_per_s": round(args.batch * world / (first_batch_ms * 1e-3), 1),
-                            "what": "one forward with every observer on (module path: min/max pass and all-reduce(MAX) per activation "
-                                    "quantiser, per-channel weight scales, one host read of the zero point per layer, then the layer, "
-                                    "torch ReLU / add between layers); not part of `value`"}}
+                            "how": first_batch_how, "module_path_ms": round(first_batch_module_ms, 2),
+                            "what": "one forward with every observer on (min/max pass and all-reduce(MAX) per activation quantiser, "
+                                    "per-channel weight scales, one host read of the zero point per layer, then the layer); `how` = "
+                                    "EagerFused: layer + shortcut add + ReLU are one int8 launch wherever the layer is on the int8 route "
+                                    "(same scales and outputs as the module path, whose time is `module_path_ms`: there torch's ReLU / add "
+                                    "run between the layers); not part of `value`"}}
            if first_batch_ms is not None else {}),
         "roofline": main_roof,
         **({"roofline_second_kernel": second_roof} if second_roof else {}),

@@ -18,7 +18,7 @@ from torch.nn import Module
 from .... import _native as N
 from .. import kernels as K
 from .. import ops
-from .._wrapper import InitState, fake_quant, int8_forward, int8_gemm_default, int8_kind, set_scale
+from .._wrapper import InitState, fake_quant, fusable_epilogue, int8_forward, int8_gemm_default, int8_kind, set_scale
 from ..utils import get_qrange
 
 
@@ -150,6 +150,20 @@ class FSPTQBase(Module):
         if cfg.get("recon_type") == "adaround":
             self.init_alpha()
         self._init.mark(self, "wt_init_state")
+
+    def forward_fused(self, input, residual=None, relu=False):
+        """`forward(input)` followed by `+ residual` and ReLU as ONE int8 launch - observers and calibration exactly as in
+        `forward` - when this layer takes its int8 route; None when it does not (the caller then runs the ops one by one;
+        whatever calibration was due has been done).  Used by dlmc.utils.fuse.EagerFused."""
+        N.require_gpu(input, self.weight)
+        if self.act_quant and not self._init.ready(self, "in_init_state"):
+            self._calibrate_input(input)
+        if self.wt_quant and not self._init.ready(self, "wt_init_state"):
+            self._calibrate_weight()
+        if not (fusable_epilogue(self) and self._int8_applicable(input)):
+            return None
+        return int8_forward(self, input, self.in_scale, self.in_offset, self.in_min_val, self.in_max_val, N.FORM_ZEROPOINT,
+                            self.wt_scale, self.wt_min_val, self.wt_max_val, residual=residual, relu=relu)
 
     def forward(self, input):
         N.require_gpu(input, self.weight)

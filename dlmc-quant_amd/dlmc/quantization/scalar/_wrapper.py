@@ -211,10 +211,15 @@ def _cached_weight_codes(mod, wt_scale, wt_lo, wt_hi, quantise, scale_key=None):
     return wq, wsum
 
 
-def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, wt_lo, wt_hi, g_in=0.0, wt_scale_key=None):
+def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, wt_lo, wt_hi, g_in=0.0, wt_scale_key=None,
+                 residual=None, relu=False):
     """Quantise the activation to integer codes (one pass, 4 B read + 1 B written per element), quantise the
     weight to KRSC int8, and contract on v_mfma_i32_32x32x32_i8 with the dequantisation fused into the epilogue.
-    Same mathematical result as F.conv2d(fake_quant(x), fake_quant(w), bias); activations travel channels_last."""
+    Same mathematical result as F.conv2d(fake_quant(x), fake_quant(w), bias); activations travel channels_last.
+    `residual` / `relu` (4-D layers with at least 64 input channels only: `fusable_epilogue`): `+ residual` and ReLU are applied
+    in the kernel's epilogue - the bits of the separate torch ops (dlmc.utils.fuse.EagerFused)."""
+    if (residual is not None or relu) and not fusable_epilogue(mod):
+        raise ValueError("int8_forward: this layer's kernel has no shortcut / ReLU epilogue")
     if not int8_layer_ok(mod):   # the 3-channel first layer: padded NHWC4 codes, one MFMA per filter row
         xpad = K.quantize_pad_nhwc4(input, in_scale.detach(), in_zp, in_lo, in_hi, act_form, mod.padding[0], g=g_in)
         if g_in:
@@ -232,7 +237,12 @@ def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, 
         out = K.conv2d_i8(flat, wq, wsum, mod.bias, in_scale, in_zp, wt_scale)
         return out.reshape(*codes.shape[:-1], out.shape[-1])
     return K.conv2d_i8(codes, wq, wsum, mod.bias, in_scale, in_zp, wt_scale, stride=mod.stride[0],
-                       padding=mod.padding[0], dilation=mod.dilation[0])
+                       padding=mod.padding[0], dilation=mod.dilation[0], residual=residual, relu=bool(relu))
+
+
+def fusable_epilogue(mod):
+    """Can this layer's int8 route take `+ residual` / ReLU into its epilogue (a 4-D layer on the generic int8 kernel)?"""
+    return mod.weight.dim() == 4 and int8_layer_ok(mod)
 
 
 # ------------------------------------------------------------------- init-state bookkeeping

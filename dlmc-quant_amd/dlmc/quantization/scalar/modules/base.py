@@ -22,7 +22,7 @@ from torch.nn import Module
 
 from .... import _native as N
 from .. import ops
-from .._wrapper import (InitState, fake_quant, int8_forward, int8_gemm_default, int8_kind, set_scale,
+from .._wrapper import (InitState, fake_quant, fusable_epilogue, int8_forward, int8_gemm_default, int8_kind, set_scale,
                         ste_scale_value)
 from ..utils import get_qrange
 
@@ -128,6 +128,25 @@ class QBase(Module):
         self._init.mark(self, "wt_init_state")
 
     # ----------------------------------------------------------------------------- forward
+    def forward_fused(self, input, residual=None, relu=False):
+        """`forward(input)` followed by `+ residual` and ReLU as ONE int8 launch (observers and calibration as in `forward`)
+        when this layer takes its int8 route; None when it does not.  Used by dlmc.utils.fuse.EagerFused."""
+        N.require_gpu(input, self.weight)
+        if not (self.int8_gemm and not torch.is_grad_enabled() and fusable_epilogue(self)):
+            return None
+        if self.qconfig["input"]["enable"] and not self._init.ready(self, "in_init_state"):
+            self._calibrate_input(input)
+        if self.qconfig["weight"]["enable"] and not self._init.ready(self, "wt_init_state") and \
+                not fnmatch(str(self.qconfig["weight"]["type"]), "*output*"):
+            self._calibrate_weight(input)
+        if not (self._init.ready(self, "wt_init_state") and self._int8_applicable()):
+            return None
+        g_i = 1 / math.sqrt(input.numel() * self.in_max_val)
+        g_w = 1 / math.sqrt(self.weight.numel() * self.wt_max_val)
+        return int8_forward(self, input, self.in_scale, None, self.in_min_val, self.in_max_val, N.FORM_QBASE,
+                            ste_scale_value(self.wt_scale, g_w), self.wt_min_val, self.wt_max_val, g_in=g_i,
+                            wt_scale_key=(self.wt_scale.data_ptr(), self.wt_scale._version, g_w), residual=residual, relu=relu)
+
     def forward(self, input):
         N.require_gpu(input, self.weight)
         if self.int8_gemm and not torch.is_grad_enabled():

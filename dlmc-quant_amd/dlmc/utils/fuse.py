@@ -622,6 +622,99 @@ def _pack_plan_weights(gm):
     return holders
 
 
+class EagerFused:
+    """The model's forward with its wrappers UNFROZEN - they observe, calibrate and re-quantise exactly as in `model(x)` - but with
+    every `layer -> (+ shortcut) -> ReLU` chain whose layer takes its int8 route evaluated by ONE launch (the int8 kernel's
+    fused epilogue) instead of the layer, torch's add and torch's ReLU: the same bits (the epilogue is the kernel the plan uses,
+    tested against the separate ops), so the scales a calibrating forward derives are identical, at roughly half the HBM traffic.
+    This is what makes the first, calibrating batch cheap (bench.py `first_batch`); the frozen plan (`fuse_inference`) is for
+    the steady state.  torch.fx reads the dataflow once (wrappers are leaves); execution is an interpreter over that graph.
+
+        fused = EagerFused(model)      # once
+        y = fused(x)                   # == model(x), bit for bit, including what the observers see"""
+
+    def __init__(self, model):
+        try:
+            graph = _Tracer().trace(model)
+        except Exception as e:
+            raise RuntimeError(f"EagerFused reads the model's dataflow with torch.fx and could not trace it ({type(e).__name__}: {e})") from e
+        self.gm = fx.GraphModule(model, graph)
+        modules = dict(self.gm.named_modules())
+        for node in list(graph.nodes):      # folded BatchNorms / eval-mode Dropout are wires
+            if node.op == "call_module" and isinstance(modules[node.target], (nn.Identity, nn.Dropout)) and len(node.args) == 1 and \
+                    not (isinstance(modules[node.target], nn.Dropout) and model.training):
+                node.replace_all_uses_with(node.args[0])
+                graph.erase_node(node)
+        self.gm.recompile()
+        self.chains = {}      # layer node -> (add node or None, shortcut node or None, relu node or None)
+        taken = set()         # an add belongs to the FIRST layer (in program order) that feeds it: the other operand is its shortcut
+        for node in graph.nodes:
+            if node.op != "call_module" or len(node.args) != 1 or node.kwargs or not hasattr(modules[node.target], "forward_fused"):
+                continue
+            add = short = relu = None
+            users = list(node.users)
+            if len(users) == 1 and _is_add(users[0]) and users[0].args[0] is not users[0].args[1]:
+                if users[0] in taken:
+                    continue
+                add = users[0]
+                taken.add(add)
+                short = add.args[1] if add.args[0] is node else add.args[0]
+                users = list(add.users)
+            if len(users) == 1 and _is_relu(users[0], modules):
+                relu = users[0]
+            if add is not None or relu is not None:
+                self.chains[node] = (add, short, relu)
+
+    def __call__(self, *args):
+        interp = _EagerInterp(self.gm, self.chains)
+        out = interp.run(*args)
+        self.last_states = {n.target: ("fused" if st == "fused" else "plain") for n, st in interp.state.items()}   # (tests, reports)
+        return out
+
+
+class _EagerInterp(fx.Interpreter):
+    def __init__(self, gm, chains):
+        super().__init__(gm)
+        self.chains = chains
+        self.add_of = {c[0]: n for n, c in chains.items() if c[0] is not None}
+        self.relu_of = {c[2]: n for n, c in chains.items() if c[2] is not None}
+        self.state = {}       # layer node -> "fused" | "plain" | ("pending", layer, x)
+
+    def _launch(self, node, layer, x, short):
+        add, _, relu = self.chains[node]
+        y = layer.forward_fused(x, residual=short, relu=relu is not None)
+        self.state[node] = "plain" if y is None else "fused"
+        return y
+
+    def run_node(self, n):
+        if n in self.chains:
+            add, short, _ = self.chains[n]
+            layer = self.fetch_attr(n.target)
+            (x,), _ = self.fetch_args_kwargs_from_env(n)
+            if add is not None and short not in self.env:      # the shortcut is computed later in program order (a downsample branch): at the add
+                self.state[n] = ("pending", layer, x)
+                return None
+            y = self._launch(n, layer, x, self.env[short] if add is not None else None)
+            return layer(x) if y is None else y
+        if n in self.add_of:
+            c = self.add_of[n]
+            st = self.state.get(c)
+            if st == "fused":
+                return self.env[c]
+            if isinstance(st, tuple):
+                _, layer, x = st
+                short = self.env[self.chains[c][1]]
+                y = self._launch(c, layer, x, short)
+                if y is not None:
+                    return y
+                self.env[c] = layer(x)           # not on the int8 route after all: the ops one by one
+        elif n in self.relu_of:
+            if self.state.get(self.relu_of[n]) == "fused":
+                (v,), _ = self.fetch_args_kwargs_from_env(n)
+                return v
+        return super().run_node(n)
+
+
 def _codes_from_blob(mod_name, blob, layer):
     """A layer's integer weight codes [K, C, R, S] (int16, on the layer's device) from an integer checkpoint of
     dlmc.utils.export (packed int4 or int8), expanded ON THE DEVICE - the plan never sees fp32 weights for that layer."""

@@ -620,3 +620,45 @@ def test_stem_and_dual_kernels_random_shapes():
         out, codes = K.conv2d_i8_dual(a, b, relu=True, emit=emit)
         same(out, want, f"dual {done} out")
         same(codes, wc, f"dual {done} codes")
+
+
+@pytest.mark.parametrize("name,family", [("resnet50", "FSPTQ"), ("resnet18", "FSPTQ"), ("resnet18", "QBase")])
+def test_eager_fused_calibrates_and_runs_like_the_model(name, family):
+    """dlmc.utils.fuse.EagerFused: the wrappers keep observing / calibrating / quantising as in `model(x)`, while every
+    layer -> (+ shortcut) -> ReLU chain on the int8 route is one launch.  A calibrating forward through it must leave EVERY
+    wrapper with the scales, offsets and init flags `model(x)` leaves, and return the same bits; so must later forwards."""
+    import copy
+    import workloads as W
+    from dlmc.utils.fuse import EagerFused
+    from dlmc.utils.merge_bn import merge_bn
+    from dlmc.utils.quantize import quantize_model
+    cfg = {"weight": {"enable": True, "type": "minmax_channel", "args": {"n_bits": 8, "signed": True}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+           "exclude_layers": [], "override_options": []}
+    if family == "QBase":      # (its int8 route: per-tensor scales, signed codes, zero offsets)
+        cfg["weight"]["type"] = "minmax_tensor"
+        cfg["input"]["args"]["signed"] = True
+    torch.manual_seed(99)
+    net = W.MODELS[name]().to(DEV).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    net = merge_bn(net, inplace=True)
+    quantize_model(net, cfg, None, family, int8_gemm=True)
+    twin = copy.deepcopy(net)
+    x = torch.relu(torch.randn(6, 3, 64, 64, device=DEV))
+    with torch.no_grad():
+        want0 = net(x)                       # calibrates, module by module
+        fused = EagerFused(twin)
+        assert len(fused.chains) >= 16 and any(c[0] is not None for c in fused.chains.values())
+        got0 = fused(x)                      # calibrates through the fused epilogues
+        assert sum(v == "fused" for v in fused.last_states.values()) >= 16, fused.last_states      # (the route was really taken)
+        sa, sb = net.state_dict(), twin.state_dict()
+        assert sa.keys() == sb.keys()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+        assert torch.equal(want0.view(torch.int32), got0.view(torch.int32))
+        want1, got1 = net(x * 0.7), fused(x * 0.7)
+        assert torch.equal(want1.view(torch.int32), got1.view(torch.int32))
+        assert torch.equal(twin(x * 0.7).view(torch.int32), got1.view(torch.int32))      # the wrappers themselves are untouched
