@@ -257,6 +257,7 @@ STEM_CASES = [  # N, C, H, W, K, R, S, stride, pad
     (2, 4, 8, 12, 32, 3, 3, 1, 1),       # four channels through the four-pixels-per-thread image quantiser (NCHW, W % 4 = 0)
     (2, 1, 8, 8, 8, 1, 1, 1, 0),         # one channel through it
     (2, 2, 6, 16, 16, 3, 3, 1, 2),       # two channels, pad 2
+    (3, 3, 10, 24, 64, 7, 7, 2, 3),      # channels_last image (odd index), three channels, W % 4 = 0: the one-pixel-per-thread quantiser
 ]
 
 
