@@ -36,6 +36,14 @@ One JSON line on rank 0.  Besides the contract fields:
   quant_work_8d        SURVEY.md 8(d)'s own accounting of the step: the bytes the reference's fake-quant passes move for this
                        batch (8 B per fake-quantised activation / weight element) over the WHOLE step's time, against 8 TB/s.
                        An equivalent rate, not HBM traffic: the fused plan never moves most of those bytes.
+  roofline_third_kernel   (round 4) the halo-tile 3x3 kernel and the generic kernel are separate families now (`conv3x3_halo` / `conv_i8`):
+                       second = the one with the larger share of the step, third = the other
+  other_configs        (default model only) BASELINE configs[3]'s network (RepVGG-A1, 512 images per GPU) and configs[4] (MobileOne-S1
+                       W4A8, 1024 per GPU) through the same pipeline, a short run each AFTER the headline region: value, ms_per_step,
+                       steps and the roofline object of the family with the largest share of a profiled step
+  collective           (N > 1) what the collective library saw: backend, world, ranks counted by an all-reduce of ones, RCCL version,
+                       the number of observer all-reduces the calibrating forward issued and the time of as many synchronous
+                       all_reduce(MAX) calls through the observers' own function; the steady state has no collective
   cpu_baseline         the CPU port of the same layer stack (oracle/), timed on this box's host cores on a bounded sample
                        (N = 1 only): all granted cores and one thread, median and min
 """
@@ -158,6 +166,7 @@ def launch_ranks(n):
 def dry_run(args, world, rank):
     """--dry-run (CPU, no GPU work; tests/test_bench_launcher.py): the launcher, the rendezvous, the barrier-bracketed timed
     region, the MAX over ranks and the one JSON line - with an empty step.  The line says so and carries no measurement."""
+    coll = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend)
@@ -170,13 +179,127 @@ def dry_run(args, world, rank):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        coll = collective_report(torch.device("cpu"), world, args.backend, 0)     # the same object a real N > 1 line carries
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": f"{args.model} fake-quant fwd images/sec", "value": 0.0, "unit": "images/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True,
                           "scaling": args.scaling, "vs_baseline": None, "dtype": "i8", "data": "dry-run: no GPU work, no measurement",
                           "config": {"workload": "dry run of the launcher and the rendezvous", "global_batch": args.batch * world,
-                                     "parallelism": f"dp{world} (batch-sharded replicas)", "backend": args.backend}}), flush=True)
+                                     "parallelism": f"dp{world} (batch-sharded replicas)", "backend": args.backend},
+                          **({"collective": coll} if coll else {})}), flush=True)
+
+
+def families(records):
+    """HIP-event durations of the profiled launches by kernel family (tag): launches, algorithmic bytes, integer operations, ms."""
+    fam = {}
+    for tag, nbytes, a, b, ops in records:
+        f = fam.setdefault(tag, {"launches": 0, "bytes": 0, "ms": 0.0, "ops": 0})
+        f["launches"] += 1
+        f["bytes"] += nbytes
+        f["ops"] += ops
+        f["ms"] += a.elapsed_time(b)
+    return fam
+
+
+FAMILY_KERNEL = {"conv_chain": "conv_chain_i8_kernel", "conv_i8": "conv_i8_mfma_kernel", "conv3x3_halo": "conv3x3_halo_i8_kernel",
+                 "conv_dw": "conv_dw3_i8_kernel", "conv_stem": "conv_stem_i8_kernel / conv_stem_pool7_i8_kernel",
+                 "conv_dwpw": "conv_dwpw_i8_kernel", "fq_image": "quantize_pad_nhwc4_kernel"}
+
+
+def family_roofline(tag, f):
+    """The roofline object of one kernel family of a profiled step: the bound is the roofline that needs more time at its peak."""
+    sec = f["ms"] * 1e-3
+    gbps, tops = f["bytes"] / sec / 1e9, f["ops"] / sec / 1e12
+    t_hbm, t_mfma = f["bytes"] / (HBM_PEAK_GBPS * 1e9), f["ops"] / (MFMA_I8_PEAK_TOPS * 1e12)
+    r = {"kernel": FAMILY_KERNEL.get(tag, tag), "launches": f["launches"], "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2),
+         "hbm": {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)},
+         "mfma": {"achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4)}}
+    b = "mfma" if t_mfma > t_hbm else "hbm"
+    return {"bound": b, "achieved": r[b]["achieved"], "peak": r[b]["peak"], "unit": r[b]["unit"], "frac": r[b]["frac"], "traffic": None, **r}
+
+
+def side_config(name, batch, args, dev, world, rank, barrier):
+    """One more network of BASELINE.json through the same pipeline as the headline (calibrating forward, frozen plan, K steps
+    bracketed by barrier + synchronize, MAX over ranks): repvgg_a1 = configs[3]'s network at its 512 images per GPU (FSPTQ W8A8,
+    deploy form), mobileone_s1 = configs[4] (W4A8 asymmetric per-channel weights, 1024 images per GPU).  One extra step in front
+    of the timed region carries the per-kernel HIP events (one stream); `roofline` is the family with the largest share of it."""
+    import workloads as W
+    from dlmc.quantization.scalar import kernels as K
+    from dlmc.utils.fuse import StreamedPlan, fuse_inference
+    from dlmc.utils.quantize import quantize_model
+    torch.manual_seed(2333)
+    model = W.MODELS[name]().to(dev).eval()
+    w4a8 = name == "mobileone_s1"
+    if w4a8:
+        quantize_model(model, json.loads(json.dumps(W4A8)), None, int8_gemm=True)
+    else:
+        from dlmc.utils.merge_bn import merge_bn
+        model = merge_bn(model, inplace=True, allow_missing=True)
+        quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=True)
+    g = torch.Generator(device=dev).manual_seed(2333 + rank)
+    x = torch.relu(torch.randn(batch, 3, 224, 224, device=dev, generator=g))
+    steps, warmup = args.other_steps, 3
+    with torch.no_grad():
+        model(x)                                      # calibration (observers + their all-reduce), untimed
+        single = fuse_inference(model)
+        plan = StreamedPlan(single, args.streams) if args.streams > 1 and not w4a8 else single
+        for _ in range(warmup):
+            plan(x)
+        single(x)
+        K.PROFILE.reset()
+        K.PROFILE.enabled = True                      # one more single-stream step with per-kernel HIP events, OUTSIDE the timed region
+        single(x)
+        K.PROFILE.enabled = False
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            plan(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    fam = {k: f for k, f in families(K.PROFILE.records).items() if f["ms"] > 0}
+    K.PROFILE.reset()
+    top = max(fam, key=lambda k: fam[k]["ms"])
+    return {"metric": f"{name} {'W4A8' if w4a8 else 'W8A8'} fake-quant fwd images/sec", "value": round(batch * world * steps / elapsed, 1),
+            "unit": "images/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup, "batch_per_gpu": batch,
+            "config": ("BASELINE configs[4]: W minmax_channel u4 asymmetric per channel (QBase family), A minmax_tensor u8, packed int4 weights"
+                       if w4a8 else "BASELINE configs[3]'s network at its per-GPU batch: FSPTQ W minmax_channel s8, A minmax_tensor u8, deploy form"),
+            "roofline": family_roofline(top, fam[top]),
+            "families_ms": {k: round(f["ms"], 3) for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
+
+
+def collective_report(dev, world, backend, calib_allreduces, reps=54):
+    """What the collective library saw (N > 1): ranks counted by an all-reduce of ones, the library's version, and the cost of the
+    calibrating forward's exchange step - `reps` synchronous all_reduce(MAX) of a packed [max | -min] pair through the very function
+    the observers call (dlmc/quantization/scalar/_wrapper.py: allreduce_minmax; ResNet-50 has 54 activation observers)."""
+    from dlmc.quantization.scalar._wrapper import allreduce_minmax
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    v, m = torch.rand(1, device=dev), torch.rand(1, device=dev)
+    allreduce_minmax(v, m)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        v, m = allreduce_minmax(v, m)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(i) for i in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001  (a version query must not fail the run)
+            ver = f"unavailable ({e})"
+    return {"backend": backend, "library": "RCCL (torch.distributed 'nccl' on ROCm)" if backend == "nccl" else backend, "world": world,
+            "ranks_seen": int(round(float(ones.item()))), "rccl_version": ver, "observer_allreduces_in_calibration": calib_allreduces,
+            "observer_allreduce_ms": round(ms, 3), "observer_allreduce_calls_timed": reps,
+            "steady_state_collectives_per_step": 0}
 
 
 def main():
@@ -217,6 +340,10 @@ def main():
                     help="timed steps whose launches carry HIP events (per-kernel durations for the roofline objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of CPU work for the all-cores leg of cpu_baseline (half of it again on one thread)")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="default model only: skip the short RepVGG-A1 b512 / MobileOne-S1 b1024 runs reported under `other_configs`")
+    ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each `other_configs` run (3 warm-up steps)")
     args = ap.parse_args()
     args.int8 = args.conv == "int8"
     if args.batch is None:
@@ -273,8 +400,10 @@ def main():
 
     args.fused = args.int8 and args.plan == "fused"
     first_batch_ms = None
+    from dlmc.quantization.scalar import _wrapper as Wr
     with torch.no_grad():
         model(x)                                 # the first forward calibrates (observer + all-reduce); not timed
+        calib_allreduces = Wr.ALLREDUCE_CALLS    # collectives this rank issued in it (one per activation observer when world > 1)
         if args.conv == "int8":
             # SURVEY 8(d) config 3 also asks for the first batch (observers on): re-arm every wrapper's observer and time ONE
             # more calibrating forward (the first one above also paid the one-time costs: code-object loads, allocator growth)
@@ -292,9 +421,13 @@ def main():
             # the same calibrating forward with every layer -> (+ shortcut) -> ReLU chain on the int8 route as ONE launch
             # (dlmc.utils.fuse.EagerFused: the wrappers observe and calibrate as above and end with identical scales - tested)
             first_batch_ms, first_batch_how = first_batch_module_ms, "module path"
+            from dlmc.utils.fuse import EagerFused
             try:
-                from dlmc.utils.fuse import EagerFused
                 eager = EagerFused(model)            # reads the dataflow once (torch.fx), as the plan does
+            except RuntimeError as e:                # a model torch.fx cannot trace keeps the module path
+                eager = None
+                print(f"[bench] EagerFused not used: {e}", file=sys.stderr)
+            if eager is not None:                    # (a kernel or launch failure in here is an error of the run, not a fallback)
                 rearm()
                 eager(x)                             # (one-time costs of this route)
                 rearm()
@@ -303,8 +436,6 @@ def main():
                 eager(x)
                 barrier()
                 first_batch_ms, first_batch_how = (time.perf_counter() - t0) * 1e3, "EagerFused"
-            except RuntimeError as e:                # a model torch.fx cannot trace keeps the module path
-                print(f"[bench] EagerFused not used: {e}", file=sys.stderr)
         if args.fused:
             from dlmc.utils.fuse import fuse_inference
             model = fuse_inference(model)        # scales are frozen from here on (BASELINE configs[2]: steady state)
@@ -334,13 +465,16 @@ def main():
     elapsed = float(t.item())
 
     # per-kernel-family HIP-event durations of the timed region (rank 0's launches)
-    fam = {}
-    for tag, nbytes, a, b in K.PROFILE.records:
-        f = fam.setdefault(tag, {"launches": 0, "bytes": 0, "ms": 0.0})
-        f["launches"] += 1
-        f["bytes"] += nbytes
-        f["ms"] += a.elapsed_time(b)
+    fam = families(K.PROFILE.records)
+    coll = collective_report(dev, world, args.backend, calib_allreduces) if world > 1 else None
+
+    def other_configs():
+        """BASELINE configs[3]'s and [4]'s networks, a short run each after the headline region (every rank takes part)."""
+        if not (args.other_configs and args.fused and args.model == "resnet50"):
+            return None
+        return {name: side_config(name, b, args, dev, world, rank, barrier) for name, b in (("repvgg_a1", 512), ("mobileone_s1", 1024))}
     if rank != 0:
+        other_configs()
         if world > 1:
             dist.destroy_process_group()
         return
@@ -381,30 +515,17 @@ def main():
                     return int((2 * v["FETCH_SIZE"]["mean_KiB"] + v["WRITE_SIZE"]["mean_KiB"]) * 1024), os.path.basename(path)
         return None, None
 
-    empty = {"launches": 0, "bytes": 0, "ms": 0.0}
+    empty = {"launches": 0, "bytes": 0, "ms": 0.0, "ops": 0}
     fq = fam.get("fq_tensor", empty)
     fq_roof = roof("fq_tensor", fq, "fq_tensor_kernel<ZEROPOINT> (per-tensor activation fake-quant"
                    + (", int8 code emission: 5 B/elem)" if args.int8 else ": 8 B/elem)"))
-    conv = fam.get("conv_i8", empty)
+    conv = fam.get("conv_i8", empty)              # the generic int8 kernel: 1x1 layers outside chains, dual kernels, fc
+    halo = fam.get("conv3x3_halo", empty)         # the halo-tile 3x3 kernel (csrc/conv3x3_i8.hip): its own family since round 4
     chain = fam.get("conv_chain", empty)          # block end + next 1x1 in one kernel (csrc/conv_chain_i8.hip)
-    conv_ops = chain_ops = 0
-    if conv["ms"] > 0 or chain["ms"] > 0:
-        table = W.layer_table(W.MODELS[args.model](), torch.zeros(1, 3, 224, 224))
-        dense = lambda r: len(r[3]) == 2 or r[2][1] == r[3][1]     # noqa: E731  (groups = 1)
-        # the layers on the matrix-core kernel: dense, C % 64 == 0 (the plan zero-pads MobileOne's 96-channel tensors: counted as they are)
-        macs = sum(r[4] for r in table if dense(r) and (r[3][1] % 64 == 0 or (w4a8 and r[3][1] > 4)))
-        chain_macs = 0
-        if chain["ms"] > 0:
-            from dlmc.utils.fuse import ChainInt8Layer
-            by_shape = {r[3]: r[4] for r in table}       # (in ResNets a weight shape occurs at one resolution only)
-            plan_mod = model.plan if hasattr(model, "plan") else model
-            chain_macs = sum(by_shape[tuple(p.layer.weight.shape)] for c in plan_mod.modules() if isinstance(c, ChainInt8Layer)
-                             for p in (c.main, c.short, c.b) if p is not None)
-        conv_ops = 2 * (macs - chain_macs) * args.batch * psteps
-        chain_ops = 2 * chain_macs * args.batch * psteps
+    conv_ops, chain_ops = conv.get("ops", 0), chain.get("ops", 0)     # 2 x MACs, recorded per launch (kernels.PROFILE)
     # `roofline` describes the kernel of this project with the largest share of the timed region
-    second_roof = None
-    if max(conv["ms"], chain["ms"]) > fq["ms"]:
+    second_roof = third_roof = None
+    if max(conv["ms"], chain["ms"], halo["ms"]) > fq["ms"]:
         if args.fused:
             note = ("algorithmic bytes per launch = int8 input + int8 weights + what the epilogue moves (1 B/elem codes, "
                     "4 B/elem fp32 output where a shortcut / pool needs it, 4 B/elem residual read)")
@@ -414,7 +535,14 @@ def main():
                                                    "next block's first 1x1 convolution in one launch; the code tensor between them stays in LDS)",
                               "algorithmic bytes per launch = int8 inputs + int8 weights of both (three) convolutions + 4 B/elem fp32 shortcut read "
                               "+ 4 B/elem fp32 output (1 B/elem codes at stage ends) + the second convolution's codes", ops=chain_ops)
-            main_roof, second_roof = (chain_roof, conv_roof) if chain["ms"] > conv["ms"] else (conv_roof, chain_roof if chain["ms"] > 0 else None)
+            ranked = [(chain["ms"], chain_roof), (conv["ms"], conv_roof)]
+            if halo["ms"] > 0:
+                ranked.append((halo["ms"], roof("conv3x3_halo", halo, "conv3x3_halo_i8_kernel (3x3 / pad 1 layers of stride 1 or 2 that emit only their "
+                                                "consumer's codes: linear-frame stencil over a halo tile staged once per 64-channel chunk)",
+                                                "algorithmic bytes per launch = int8 input + int8 weights + 1 B/elem codes out", ops=halo["ops"])))
+            ranked = [r for ms, r in sorted(ranked, key=lambda t: -t[0]) if ms > 0]
+            main_roof, second_roof = ranked[0], (ranked[1] if len(ranked) > 1 else None)
+            third_roof = ranked[2] if len(ranked) > 2 else None
         else:
             main_roof = roof("conv_i8", conv, "conv_i8_mfma_kernel (fused int8-dequant x GEMM conv/linear, fp32 NHWC out)",
                              "algorithmic bytes = int8 input + int8 weights + fp32 output per launch; the 1x1 layers are bound by "
@@ -425,12 +553,12 @@ def main():
     if args.fused and dw["ms"] > 0:
         dw_roof = roof("conv_dw", dw, "conv_dw3_i8_kernel (depthwise 3x3 on activation codes, fused ReLU + the consumer's codes)",
                        "algorithmic bytes per launch = 1 B/elem codes in + 1 B/elem codes out (+ 4 B/elem where an fp32 output is kept)")
-        if dw["ms"] > max(conv["ms"], chain["ms"]):
+        if dw["ms"] > max(conv["ms"], chain["ms"], halo["ms"]):
             main_roof, second_roof = dw_roof, main_roof
         elif second_roof is None:
             second_roof = dw_roof
-    if args.fused and max(conv["ms"], chain["ms"]) > fq["ms"] and args.model == "resnet50" and args.batch == 512:
-        for r in (main_roof, second_roof):
+    if args.fused and max(conv["ms"], chain["ms"], halo["ms"]) > fq["ms"] and args.model == "resnet50" and args.batch == 512:
+        for r in (main_roof, second_roof, third_roof):
             if r is None:
                 continue
             r["traffic"], src = pmc_traffic(r["kernel"].split(" ")[0])
@@ -454,7 +582,7 @@ def main():
         torch.cuda.synchronize()
         K.PROFILE.enabled = False
         f2 = {"launches": 0, "bytes": 0, "ms": 0.0}
-        for tag, nbytes, e0, e1 in K.PROFILE.records:
+        for tag, nbytes, e0, e1, _ in K.PROFILE.records:
             f2["launches"] += 1
             f2["bytes"] += nbytes
             f2["ms"] += e0.elapsed_time(e1)
@@ -490,6 +618,7 @@ def main():
            if first_batch_ms is not None else {}),
         "roofline": main_roof,
         **({"roofline_second_kernel": second_roof} if second_roof else {}),
+        **({"roofline_third_kernel": third_roof} if third_roof else {}),
         "roofline_fake_quant": fq_roof,
         "quant_path": {"images_per_s": round(args.batch * psteps / (qms * 1e-3), 1) if qms else None,
                        "GBps": round(qbytes / (qms * 1e-3) / 1e9, 1) if qms else None,
@@ -509,13 +638,20 @@ def main():
                                 "note": "SURVEY.md 8(d) accounting: bytes the reference's stand-alone fake-quant passes move per step "
                                         "/ the whole step's time (convolutions included); an equivalent rate - in the fused plan "
                                         "the quantisers run in the conv epilogues and most of these bytes never exist"}
-    if conv["ms"] + chain["ms"] > 0:     # both int8 matrix-core kernels together
-        out["conv_i8"] = {"launches": conv["launches"] + chain["launches"], "ms_per_step": round((conv["ms"] + chain["ms"]) / psteps, 3),
-                          "GBps": round((conv["bytes"] + chain["bytes"]) / ((conv["ms"] + chain["ms"]) * 1e-3) / 1e9, 1),
-                          "TOPs": round((conv_ops + chain_ops) / ((conv["ms"] + chain["ms"]) * 1e-3) / 1e12, 1),
+    if conv["ms"] + chain["ms"] + halo["ms"] > 0:     # the int8 matrix-core kernels together
+        ms3 = conv["ms"] + chain["ms"] + halo["ms"]
+        out["conv_i8"] = {"launches": conv["launches"] + chain["launches"] + halo["launches"], "ms_per_step": round(ms3 / psteps, 3),
+                          "GBps": round((conv["bytes"] + chain["bytes"] + halo["bytes"]) / (ms3 * 1e-3) / 1e9, 1),
+                          "TOPs": round((conv_ops + chain_ops + halo.get("ops", 0)) / (ms3 * 1e-3) / 1e12, 1),
                           "peak_TOPs_dense_i8": MFMA_I8_PEAK_TOPS}
+    if coll is not None:
+        out["collective"] = coll
+    other = other_configs()
+    if other is not None:
+        out["other_configs"] = other
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_batch, fold_bn=not args.keep_bn, halfnormal=args.input == "halfnormal")
+        out["cpu_baseline"] = cpu_baseline(args.cpu_batch, budget_s=args.cpu_budget, fold_bn=not args.keep_bn,
+                                           halfnormal=args.input == "halfnormal")
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

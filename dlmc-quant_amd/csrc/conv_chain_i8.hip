@@ -391,7 +391,11 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
       if constexpr (LDST) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) tstage[tw[j]] = v[4 * g + j];
+        // (the read takes what OTHER lanes of this wave wrote: LDS operations of a wave execute in order, and the compiler must
+        //  keep them in this order - a memory clobber between the writes and the read, and after the read, costs no instruction)
+        asm volatile("" ::: "memory");
         y = *reinterpret_cast<const f32x4*>(tstage + trd);
+        asm volatile("" ::: "memory");
       } else {
         quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
         y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};

@@ -674,9 +674,11 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   if (!forced && ep.w_off && plan.bn == 64 && K % 192 == 0 && plan.swap && ep.codes && !out && !ep.residual && aligned16(ep.codes)) plan.bn = 192;
   if (plan.halo && conv3x3_halo_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
     return conv3x3_halo_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st);
-  if (plan.bn != 64 && plan.bn != 128 && plan.bn != 256 && !(plan.bn == 192 && ep.w_off)) return DLMCQ_EINVAL;
   // 256-wide tiles exist for the swapped codes-only layers only (one third fewer operand bytes per MAC, two workgroups per CU)
   const bool swap_ok = plan.swap && ep.codes && !out && !ep.residual && K % plan.bn == 0 && aligned16(ep.codes);
+  // (192-wide tiles: the swapped asymmetric codes-only instantiation is the only one - a forced plan that asks for them anywhere
+  //  else would compute nblk_n for 192 and launch the 128-wide kernel, leaving channels unwritten)
+  if (plan.bn != 64 && plan.bn != 128 && plan.bn != 256 && !(plan.bn == 192 && ep.w_off && swap_ok && !seg2)) return DLMCQ_EINVAL;
   if (plan.bn == 256 && (seg2 || ep.w_off || !swap_ok)) {
     if (forced) return DLMCQ_EINVAL;
     ConvPlan p2 = plan;                  // (fp32 outputs, shortcuts, asymmetric weights: the 128-wide kernels)

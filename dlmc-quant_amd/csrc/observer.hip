@@ -477,6 +477,58 @@ extern "C" int dlmcq_qparams_from_minmax(const float* vmax, const float* vmin, f
   return launch_status();
 }
 
+// ---- LSQ initialisation: 2 * mean|x| / sqrt(Qp) (modules/base.py:84-85,118-121) ----
+namespace dlmcq {
+constexpr int LSQ_WGS = 2048;   // one-wave workgroups, persistent over the tensor
+
+__global__ __launch_bounds__(64) void abs_sum_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * 64;
+  double acc = 0.0;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = __builtin_nontemporal_load(x4 + i);
+    acc += (double)__builtin_fabsf(v.x) + (double)__builtin_fabsf(v.y) + (double)__builtin_fabsf(v.z) + (double)__builtin_fabsf(v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) acc += (double)__builtin_fabsf(x[(n4 << 2) + threadIdx.x]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(DLMCQ_BLOCK) void lsq_finalize_kernel(const double* __restrict__ part, int np, int64_t n, float sqrt_qmax,
+                                                                   float* __restrict__ scale) {
+  __shared__ double sh[DLMCQ_BLOCK];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < np; i += DLMCQ_BLOCK) a += part[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = DLMCQ_BLOCK / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float mean = (float)sh[0] / (float)n;     // x.abs().mean(): fp32 sum / numel
+    scale[0] = (2.0f * mean) / sqrt_qmax;           // 2 * mean / math.sqrt(Qp): true division (tensor / python scalar on the CPU)
+  }
+}
+}  // namespace dlmcq
+
+extern "C" size_t dlmcq_lsq_init_scratch_bytes(int64_t n) { return n < 0 ? 0 : (size_t)LSQ_WGS * sizeof(double); }
+
+extern "C" int dlmcq_lsq_init_f32(const float* x, float* scale, int64_t n, float sqrt_qmax, void* scratch, size_t scratch_bytes,
+                                  dlmcq_stream_t stream) {
+  if (n < 1 || !x || !scale || !(sqrt_qmax > 0.0f)) return DLMCQ_EINVAL;   // (the mean of nothing has no value: torch gives NaN, we refuse)
+  if (!scratch || scratch_bytes < (size_t)LSQ_WGS * sizeof(double)) return DLMCQ_ESCRATCH;
+  if (!aligned16(x) || (((uintptr_t)scratch) & 7u)) return DLMCQ_EALIGN;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t want = ((n >> 2) + 63) / 64;
+  const int np = (int)(want < 1 ? 1 : (want > LSQ_WGS ? LSQ_WGS : want));
+  hipLaunchKernelGGL(abs_sum_kernel, dim3(np), dim3(64), 0, st, x, n, static_cast<double*>(scratch));
+  hipLaunchKernelGGL(lsq_finalize_kernel, dim3(1), dim3(DLMCQ_BLOCK), 0, st, static_cast<const double*>(scratch), np, n, sqrt_qmax, scale);
+  return launch_status();
+}
+
 extern "C" int dlmcq_span_scale_f32(const float* vmax, const float* vmin, float* scale, int64_t channels, float span,
                                     int32_t min_is_negated, dlmcq_stream_t stream) {
   if (channels < 1 || !(span > 0.0f)) return DLMCQ_EINVAL;

@@ -9,7 +9,19 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DLMCQ_LIBRARY") or os.path.join(os.path.dirname(_HERE), "libdlmcq.so")   # (override: A/B builds, tools/)
+import sys
+
+_PRODUCT = os.path.join(os.path.dirname(_HERE), "libdlmcq.so")
+# Another build of the library (same-box A/B timing, the lab library of tools/) is loaded ONLY when the caller names it AND
+# declares itself a lab tool (DLMCQ_LAB_TOOLS=1; tools/*.py and tools/*.sh set both), and the path is printed: a stale
+# DLMCQ_LIBRARY in a user's environment does not swap the product library silently - it is reported and ignored.
+_OVERRIDE = os.environ.get("DLMCQ_LIBRARY")
+LAB_OVERRIDE = bool(_OVERRIDE) and os.environ.get("DLMCQ_LAB_TOOLS") == "1"
+if _OVERRIDE and not LAB_OVERRIDE:
+    print(f"[dlmc] DLMCQ_LIBRARY={_OVERRIDE} ignored (set DLMCQ_LAB_TOOLS=1 to load a lab / A-B build); loading {_PRODUCT}", file=sys.stderr)
+LIB_PATH = _OVERRIDE if LAB_OVERRIDE else _PRODUCT
+if LAB_OVERRIDE:
+    print(f"[dlmc] lab override: loading {LIB_PATH} instead of the product library", file=sys.stderr)
 
 # enums of include/dlmcq.h
 FORM_EMULATE, FORM_QBASE, FORM_ZEROPOINT, FORM_SYMMETRIC, FORM_ROOTQ_ACT = range(5)
@@ -32,6 +44,8 @@ SIGNATURES = {
     "dlmcq_minmax_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i32, _p, _sz, _p]),
     "dlmcq_qparams_from_minmax": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f32, _p]),
     "dlmcq_span_scale_f32": (ctypes.c_int, [_p, _p, _p, _i64, _f32, _i32, _p]),
+    "dlmcq_lsq_init_scratch_bytes": (_sz, [_i64]),
+    "dlmcq_lsq_init_f32": (ctypes.c_int, [_p, _p, _i64, _f32, _p, _sz, _p]),
     "dlmcq_observe_qparams_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _p, _sz, _p]),
     "dlmcq_pack_int4": (ctypes.c_int, [_p, _p, _i64, _p]),
     "dlmcq_unpack_int4": (ctypes.c_int, [_p, _p, _i64, _i32, _p]),
@@ -101,7 +115,7 @@ def _load():
         try:
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         except AttributeError:
-            if os.environ.get("DLMCQ_LIBRARY"):   # an older build named for an A/B run: calls to what it lacks fail there
+            if LAB_OVERRIDE:   # an older build named for an A/B run: calls to what it lacks fail there
                 continue
             raise
         fn.restype, fn.argtypes = res, args

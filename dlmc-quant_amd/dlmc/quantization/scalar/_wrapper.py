@@ -113,6 +113,9 @@ def sync_enabled():
     return os.environ.get("DLMC_SYNC_OBSERVER", "1") != "0"
 
 
+ALLREDUCE_CALLS = 0     # collectives actually issued by this process (bench.py reports the count of the calibrating forward)
+
+
 def allreduce_minmax(vmax, neg_vmin=None, group=None):
     """The path's only collective (C2): one all_reduce(MAX) over the packed [max | -min] vector.
     Exact and order-independent, so every rank ends with the single-GPU result over the whole batch.
@@ -120,6 +123,8 @@ def allreduce_minmax(vmax, neg_vmin=None, group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return vmax, neg_vmin
+    global ALLREDUCE_CALLS
+    ALLREDUCE_CALLS += 1
     n = vmax.numel()
     buf = vmax.reshape(-1) if neg_vmin is None else torch.cat([vmax.reshape(-1), neg_vmin.reshape(-1)])
     buf = buf.contiguous()

@@ -13,7 +13,7 @@ from ..._native import (CODES_I8, CODES_NONE, CODES_P4, FORM_EMULATE, FORM_QBASE
                         Y_CODES, Y_DEQUANT)
 
 __all__ = ["fake_quant", "dequant_codes", "dequant", "minmax", "observe_qparams", "qparams_from_minmax",
-           "span_scale", "l2norm_step", "adaround_weight", "adaround_weight_backward", "quantize_weight_krsc", "conv2d_i8", "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
+           "span_scale", "lsq_init", "l2norm_step", "adaround_weight", "adaround_weight_backward", "quantize_weight_krsc", "conv2d_i8", "pack_int4", "unpack_int4", "fake_quant_backward", "rootq_weight", "geometry", "channel_shape",
            "PROFILE"]
 
 
@@ -23,19 +23,19 @@ class _Profile:
 
     def __init__(self):
         self.enabled = False
-        self.records = []  # (tag, algorithmic_bytes, start_event, stop_event)
+        self.records = []  # (tag, algorithmic_bytes, start_event, stop_event, integer operations = 2 x MACs or 0)
 
     def reset(self):
         self.records = []
 
-    def launch(self, tag, nbytes, fn):
+    def launch(self, tag, nbytes, fn, ops=0):
         if not self.enabled:
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         r = fn()
         b.record()
-        self.records.append((tag, nbytes, a, b))
+        self.records.append((tag, nbytes, a, b, ops))
         return r
 
 
@@ -228,6 +228,24 @@ def span_scale(vmax, neg_vmin, span):
     scale = torch.empty(vmax.numel(), dtype=torch.float32, device=vmax.device)
     N.check(N.lib.dlmcq_span_scale_f32(N.ptr(vmax), N.ptr(neg_vmin), N.ptr(scale), vmax.numel(), float(span), 1,
                                        N.stream_ptr()))
+    return scale
+
+
+def lsq_init(x, qmax):
+    """LSQ's first-call scale 2 * mean|x| / sqrt(Qp) (modules/base.py:84-85,118-121) as one read of `x` on the device
+    (dlmcq_lsq_init_f32: deterministic double-precision sum, the reference's fp32 chain and a true division).  Returns [1] fp32."""
+    import math
+    N.require_gpu(x)
+    x = x.detach()
+    if x.dtype != torch.float32:
+        x = x.float()
+    if not (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))):
+        x = x.contiguous()       # (an element-order-free reduction: any dense layout is read in place)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    nb = N.lib.dlmcq_lsq_init_scratch_bytes(x.numel())
+    scr = _scratch(nb, x.device)
+    N.check(N.lib.dlmcq_lsq_init_f32(N.ptr(x), N.ptr(scale), x.numel(), float(torch.tensor(math.sqrt(qmax), dtype=torch.float32)),
+                                     N.ptr(scr), scr.numel() * 4, N.stream_ptr()))
     return scale
 
 
@@ -433,6 +451,12 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
     args = (N.ptr(codes), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),
             n, h, w_, c, K, R, S, int(stride), int(padding), int(dilation), int(codes.dtype == torch.uint8))
     out_elems = n * K * P * Q
+    ops = 2 * out_elems * c * R * S
+    # which kernel of the library takes the launch (conv3x3_halo_applies, csrc/conv3x3_i8.hip): the profile tag only
+    halo = (not linear and (R, S) == (3, 3) and stride in (1, 2) and padding == 1 and dilation == 1 and not want_out and emit is not None
+            and residual is None and w_offset is None and c % 64 == 0 and K % 64 == 0 and (stride == 1 or (h | w_) & 1 == 0)
+            and (stride == 1 or Q + 1 <= 62) and not (stride == 2 and c == 64 and K != 64) and Q + 1 <= 120)
+    tag = "conv3x3_halo" if halo else "conv_i8"
     if fused:
         out_codes = q_scale = q_zp = None
         lo = hi = form = 0
@@ -452,16 +476,16 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
             lo, hi, form, g = emit.lo, emit.hi, emit.form_arg, emit.g
         nbytes = codes.numel() + wq.numel() + out_elems * (4 * (out is not None) + 4 * (residual is not None) + (emit is not None))
         if w_offset is not None:
-            PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_asym(
+            PROFILE.launch(tag, nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_asym(
                 *args[:8], N.ptr(w_offset), *args[8:], N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp),
-                lo, hi, form, g, N.stream_ptr())))
+                lo, hi, form, g, N.stream_ptr())), ops)
         else:
-            PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_fused(
+            PROFILE.launch(tag, nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_fused(
                 *args, N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g,
-                N.stream_ptr())))
+                N.stream_ptr())), ops)
         return (out, out_codes) if emit is not None else out
     args = args + (N.stream_ptr(),)
-    PROFILE.launch("conv_i8", codes.numel() + out_elems * 4 + wq.numel(), lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(*args)))
+    PROFILE.launch(tag, codes.numel() + out_elems * 4 + wq.numel(), lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(*args)), ops)
     return out
 
 
@@ -500,7 +524,7 @@ def conv2d_dw_i8(codes, wq, bias, in_scale, in_zp, w_scale, w_offset=None, strid
                    lambda: N.check(N.lib.dlmcq_conv2d_dw_i8_nhwc(
                        N.ptr(codes), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale), N.ptr(w_offset),
                        n, h, w_, c, R, S, int(stride), int(padding), int(codes.dtype == torch.uint8), int(bool(relu)), N.ptr(out_codes),
-                       N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())))
+                       N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())), 2 * oe * R * S)
     return (out, out_codes) if emit is not None else out
 
 
@@ -554,7 +578,8 @@ def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True):
         N.ptr(ca), N.ptr(a["wq"]), N.ptr(out), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa),
         n, h, w_, ch, K_, R, S, st, pd, dl, uns,
         N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2, ch2, R2, S2, st2, pd2, dl2,
-        uns2, int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())))
+        uns2, int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())),
+        2 * oe * (ch * R * S + ch2 * R2 * S2))
     return (out, out_codes) if emit is not None else out
 
 
@@ -630,7 +655,8 @@ def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_co
         N.ptr(c), N.ptr(a["wq"]), N.ptr(out), N.ptr(b1), N.ptr(a["wsum"]), N.ptr(si), N.ptr(zp), N.ptr(ws1), m, ch, K_,
         int(c.dtype == torch.uint8), N.ptr(residual), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi,
         emit.form, emit.g, N.ptr(w2t), N.ptr(b2), N.ptr(b["wsum"]), N.ptr(ws2), K2, int(bool(relu2)), N.ptr(codes2),
-        N.ptr(qs2), N.ptr(qz2), emit2.lo, emit2.hi, emit2.form_arg | w2flag, emit2.g, int(rows_per_tile), N.stream_ptr())))
+        N.ptr(qs2), N.ptr(qz2), emit2.lo, emit2.hi, emit2.form_arg | w2flag, emit2.g, int(rows_per_tile), N.stream_ptr())),
+        2 * m * K_ * (ch + K2))
     return out, codes, codes2
 
 
@@ -689,7 +715,8 @@ def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_cod
         int(ca.dtype == torch.uint8), N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2,
         ch2, st2, int(cb.dtype == torch.uint8), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi, emit.form, emit.g,
         N.ptr(w3t), N.ptr(b3), N.ptr(c3["wsum"]), N.ptr(ws3), K3, int(bool(relu3)), N.ptr(codes3), N.ptr(qs3), N.ptr(qz3), emit3.lo,
-        emit3.hi, emit3.form_arg | w3flag, emit3.g, int(rows_per_tile), N.stream_ptr())))
+        emit3.hi, emit3.form_arg | w3flag, emit3.g, int(rows_per_tile), N.stream_ptr())),
+        2 * m * K_ * (ch + ch2 + K3))
     return out, codes, codes3
 
 
@@ -773,13 +800,15 @@ def conv2d_i8_stem(xpad, wq, wsum, bias, in_scale, in_zp, w_scale, S, stride=1, 
                        lambda: N.check(N.lib.dlmcq_conv2d_i8_stem_asym(
                            N.ptr(xpad), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),
                            N.ptr(w_offset), int(channels), n, hp, wp, K_, R, int(S), int(stride), int(xpad.dtype == torch.uint8),
-                           int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())))
+                           int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())),
+                       2 * n * K_ * ((hp - R) // stride + 1) * ((wp - S) // stride + 1) * R * S * int(channels))
         return (out, out_codes) if emit is not None else out
     PROFILE.launch("conv_stem", xpad.numel() + wq.numel() + oe * (4 * want_out + (emit is not None)),
                    lambda: N.check((N.lib.dlmcq_conv2d_i8_stem_pool_fused if pool else N.lib.dlmcq_conv2d_i8_stem_fused)(
                        N.ptr(xpad), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(wsum), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale),
                        n, hp, wp, K_, R, int(S), int(stride), int(xpad.dtype == torch.uint8), int(bool(relu)), N.ptr(out_codes),
-                       N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())))
+                       N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())),
+                   2 * n * K_ * ((hp - R) // stride + 1) * ((wp - S) // stride + 1) * R * S * 3)
     return (out, out_codes) if emit is not None else out
 
 

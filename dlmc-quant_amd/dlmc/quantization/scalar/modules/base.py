@@ -21,6 +21,7 @@ import torch
 from torch.nn import Module
 
 from .... import _native as N
+from .. import kernels as K
 from .. import ops
 from .._wrapper import (InitState, fake_quant, fusable_epilogue, int8_forward, int8_gemm_default, int8_kind, set_scale,
                         ste_scale_value)
@@ -100,8 +101,8 @@ class QBase(Module):
         cfg = self.qconfig["input"]
         x = input.detach()
         if fnmatch(str(cfg["type"]), "LSQ"):
-            # LSQ init 2*mean|x|/sqrt(Qp) (base.py:84-85): one-off, plain device reductions
-            scale = 2 * x.abs().mean() / math.sqrt(self.in_max_val)
+            # LSQ init 2*mean|x|/sqrt(Qp) (base.py:84-85): one read of x on the device (dlmcq_lsq_init_f32)
+            scale = K.lsq_init(x, self.in_max_val)
             offset = torch.zeros((), device=x.device)
         else:
             kw = dict(cfg["args"])
@@ -119,7 +120,7 @@ class QBase(Module):
         if fnmatch(str(cfg["type"]), "*output*"):
             scale, offset = ops.get_qparams_output(input.detach(), w, self, qtype=cfg["type"], **cfg["args"])
         elif fnmatch(str(cfg["type"]), "LSQ"):
-            scale = 2 * w.abs().mean() / math.sqrt(self.wt_max_val)
+            scale = K.lsq_init(w, self.wt_max_val)         # base.py:118-121
             offset = torch.zeros((), device=w.device)
         else:
             scale, offset = ops.get_qparams_tensor(w, qtype=cfg["type"], **cfg["args"])

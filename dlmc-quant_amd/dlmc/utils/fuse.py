@@ -553,6 +553,10 @@ def _is_add(node):
     return False
 
 
+def _inplace_add(node):
+    return (node.op == "call_method" and node.target == "add_") or (node.op == "call_function" and node.target is operator.iadd)
+
+
 def _is_relu(node, modules):
     if node.op == "call_module":
         return type(modules.get(node.target)) is nn.ReLU
@@ -631,7 +635,12 @@ class EagerFused:
     the steady state.  torch.fx reads the dataflow once (wrappers are leaves); execution is an interpreter over that graph.
 
         fused = EagerFused(model)      # once
-        y = fused(x)                   # == model(x), bit for bit, including what the observers see"""
+        y = fused(x)                   # == model(x), bit for bit, including what the observers see
+
+    Limits (each keeps `y == model(x)` by NOT fusing): a shortcut that is not an fp32 tensor of the layer's exact output shape
+    (broadcast adds, other dtypes) runs layer, add and ReLU one by one; an in-place add INTO the shortcut (`short += layer(x)`) is
+    left to torch, because the fused launch would not mutate `short`.  Not preserved on fused chains: forward hooks registered on
+    the wrapper, the add or the ReLU (`forward_fused` is called directly and the add / ReLU never run as modules)."""
 
     def __init__(self, model):
         try:
@@ -656,6 +665,8 @@ class EagerFused:
             if len(users) == 1 and _is_add(users[0]) and users[0].args[0] is not users[0].args[1]:
                 if users[0] in taken:
                     continue
+                if _inplace_add(users[0]) and users[0].args[0] is not node:
+                    continue      # `short += layer(x)` mutates the shortcut tensor, which other readers may hold: left to torch
                 add = users[0]
                 taken.add(add)
                 short = add.args[1] if add.args[0] is node else add.args[0]
@@ -682,9 +693,31 @@ class _EagerInterp(fx.Interpreter):
 
     def _launch(self, node, layer, x, short):
         add, _, relu = self.chains[node]
+        if add is not None and not self._fusable_shortcut(layer, x, short):
+            self.state[node] = "plain"       # a broadcast / differently shaped / non-fp32 shortcut: the ops one by one
+            return None
         y = layer.forward_fused(x, residual=short, relu=relu is not None)
         self.state[node] = "plain" if y is None else "fused"
         return y
+
+    @staticmethod
+    def _fusable_shortcut(layer, x, short):
+        """The fused epilogue adds an fp32 tensor of exactly the layer's output shape; anything else keeps `y == model(x)` by
+        running layer, add and ReLU separately."""
+        if not isinstance(short, torch.Tensor) or short.dtype != torch.float32 or short.device != x.device:
+            return False
+        w = layer.weight
+        if w.dim() == 2:
+            return tuple(short.shape) == (*x.shape[:-1], w.shape[0])
+        if x.dim() != 4:
+            return False
+        def side(n, k, s, p, d):
+            return (n + 2 * p - d * (k - 1) - 1) // s + 1
+        p = layer.padding if not isinstance(layer.padding, str) else None
+        if p is None:
+            return False
+        return tuple(short.shape) == (x.shape[0], w.shape[0], side(x.shape[2], w.shape[2], layer.stride[0], p[0], layer.dilation[0]),
+                                      side(x.shape[3], w.shape[3], layer.stride[1], p[1], layer.dilation[1]))
 
     def run_node(self, n):
         if n in self.chains:

@@ -161,6 +161,18 @@ int dlmcq_qparams_from_minmax(const float* vmax, const float* vmin, float* scale
 int dlmcq_span_scale_f32(const float* vmax, const float* vmin, float* scale, int64_t channels, float span,
                          int32_t min_is_negated, dlmcq_stream_t stream);
 
+/*
+ * LSQ initialisation (modules/base.py:84-85 input, :118-121 weight): scale[0] = 2 * mean|x| / sqrt(Qp), the QAT flow's default
+ * first-call initialiser (example/quantization/LSQ_config.yaml, `type: "LSQ"`).  One read of x (4 B per element); per-lane
+ * double partials, a fixed-order tree over one double per workgroup (no atomics: deterministic), then the reference's own
+ * fp32 chain on the device: mean = fl32(sum) / n, 2 * mean, true IEEE division by `sqrt_qmax` (= the fp32 value of
+ * math.sqrt(Qp) the caller computed).  The only difference from the reference's CPU result is the summation order of the mean
+ * (<= a few ulp; tests state 2e-6 relative).  `scratch`: dlmcq_lsq_init_scratch_bytes() bytes, 8-byte aligned.
+ */
+size_t dlmcq_lsq_init_scratch_bytes(int64_t n);
+int dlmcq_lsq_init_f32(const float* x, float* scale, int64_t n, float sqrt_qmax, void* scratch, size_t scratch_bytes,
+                       dlmcq_stream_t stream);
+
 /* dlmcq_minmax_f32 + dlmcq_qparams_from_minmax fused into the same two launches. */
 int dlmcq_observe_qparams_f32(const float* x, float* scale, float* offset, int64_t outer,
                               int64_t channels, int64_t inner, int32_t n_bits, int32_t is_signed,

@@ -170,6 +170,31 @@ def minmax_channel(x, n_bits, signed, ch_axis=0, allow_offset=True):
     return scale.reshape(shape), offset.reshape(shape)
 
 
+def minmax_pixel(x, n_bits, signed, allow_offset=True):
+    """ops.py:142-167: one (scale, offset) per kernel position, reduced over out- and in-channels.  The unsigned branch takes
+    the minimum of |x| (ops.py:156: `tensor.abs().min`), kept as the reference has it."""
+    new_shape = [x.shape[2], x.shape[3]] if x.dim() == 4 else [x.shape[2]]
+    t = x.reshape(x.shape[0], x.shape[1], -1)
+    if signed:
+        scale = t.abs().max(dim=0)[0].max(dim=0)[0] / (2 ** (n_bits - 1) - 1)
+        offset = torch.zeros_like(scale)
+    else:
+        mn = t.abs().min(dim=0)[0].min(dim=0)[0]
+        mx = t.abs().max(dim=0)[0].max(dim=0)[0]
+        if not allow_offset:
+            assert bool((mn >= 0).all())
+            mn = torch.zeros_like(mn)
+        scale = (mx - mn) / (2 ** n_bits - 1)
+        offset = mn
+    return scale.reshape(new_shape), offset.reshape(new_shape)
+
+
+def lsq_init(x, qmax):
+    """modules/base.py:84-85 (input), :118-121 (weight): the LSQ first-call scale 2 * mean|x| / sqrt(Qp); the offset is zero."""
+    import math
+    return 2 * x.detach().abs().mean() / math.sqrt(qmax)
+
+
 def l2_loss(a, b):
     """trainer/loss/loss.py:22-24."""
     return ((a - b) ** 2).sum(axis=1).mean()

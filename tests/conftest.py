@@ -27,10 +27,11 @@ class Golden:
             self.meta = json.load(f)
         self.cases = list(self.meta["cases"])
         # cases added after golden_v1 was frozen (make_golden.py --supplement): same generator, own pair of files
-        if os.path.exists(os.path.join(d, "golden_v1_grad.npz")):
-            self.arrs.append(np.load(os.path.join(d, "golden_v1_grad.npz")))
-            with open(os.path.join(d, "golden_v1_grad.json")) as f:
-                self.cases += json.load(f)["cases"]
+        for extra in ("golden_v1_grad", "golden_v2"):      # --supplement (round 2), --supplement2 (round 4: LSQ init, minmax_pixel)
+            if os.path.exists(os.path.join(d, extra + ".npz")):
+                self.arrs.append(np.load(os.path.join(d, extra + ".npz")))
+                with open(os.path.join(d, extra + ".json")) as f:
+                    self.cases += json.load(f)["cases"]
         self.arr = self.arrs[0]
 
     def of_kind(self, kind):

@@ -6,7 +6,9 @@ Run ONLY in the build container, where the reference checkout is mounted at
 output of this script: `tests/golden/golden_v1.npz` (inputs + expected outputs) and
 `tests/golden/golden_v1.json` (case descriptors).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                  # golden_v1
+    python tests/golden/make_golden.py --supplement     # golden_v1_grad (round 2)
+    python tests/golden/make_golden.py --supplement2    # golden_v2: LSQ initialisation, minmax_pixel (round 4)
 
 How the reference is imported: the package does not import through
 its normal graph (`trainer/__init__.py` pulls torchvision and five missing modules), so
@@ -604,6 +606,87 @@ def case_weight_transforms():
                           has_identity=any(k.startswith("rbr_identity") for k in pre)))
 
 
+# ------------------------------------------------- round-4 supplement: LSQ initialisation, minmax_pixel
+def case_lsq():
+    """`type: "LSQ"` through QConv2d / QLinear (modules/base.py:84-85 input, :118-121 weight): the QAT flow's default first-call
+    initialiser 2 * mean|x| / sqrt(Qp) (example/quantization/LSQ_config.yaml: W s3, A u3), then the QBase forward with it.  The
+    reference's LSQ branch allocates its zero offsets on device('cuda'): torch.zeros is wrapped for the duration of the forward
+    (the same patch fsptq_init uses for FSPTQBase.initialize)."""
+    orig = torch.zeros
+
+    def zeros_cpu(*a, **k):
+        k.pop("device", None)
+        return orig(*a, **k)
+    idx = 0
+    for kind in ("conv", "conv_s2", "linear"):
+        for (w_signed, w_bits), (i_signed, i_bits), w_type, i_type in (
+                ((True, 3), (False, 3), "LSQ", "LSQ"),              # LSQ_config.yaml
+                ((True, 8), (True, 8), "LSQ", "LSQ"),
+                ((True, 4), (False, 8), "LSQ", "minmax_tensor"),    # only the weights by LSQ
+                ((True, 8), (False, 4), "minmax_tensor", "LSQ")):   # only the input by LSQ
+            g = gen(7000 + idx)
+            m, x = make_layer(kind, g)
+            if not i_signed:
+                x = torch.relu(x)
+            qcfg = {"input": {"enable": True, "type": i_type, "args": {"n_bits": i_bits, "signed": i_signed}},
+                    "weight": {"enable": True, "type": w_type, "args": {"n_bits": w_bits, "signed": w_signed}},
+                    "momentum": 0.1}
+            cls = modules.QLinear if kind == "linear" else modules.QConv2d
+            q = swap(cls, m, qcfg)
+            cap = Capture(q)
+            torch.zeros = zeros_cpu
+            try:
+                with torch.no_grad():
+                    out1 = q(x)
+                    in1, wt1 = cap.input, cap.weight
+                    x2 = x * 0.7 + 0.05
+                    out2 = q(x2)
+                    in2 = cap.input
+            finally:
+                torch.zeros = orig
+            name = f"lsq{idx}"
+            put(name, x=x, x2=x2, weight=m.weight, bias=(m.bias if m.bias is not None else torch.zeros(0)),
+                in_scale=q.in_scale, in_offset=q.in_offset.to(torch.float32).reshape(-1),
+                wt_scale=q.wt_scale, wt_offset=q.wt_offset.to(torch.float32).reshape(-1),
+                fq_input=in1, fq_weight=wt1, fq_input2=in2, out=out1, out2=out2)
+            CASES.append(dict(name=name, kind="lsq", layer=kind, qconfig=qcfg, state_keys=sorted(q.state_dict().keys())))
+            idx += 1
+
+
+def case_minmax_pixel():
+    """ops.py:142-167 quantize_minmax_pixel: one (scale, offset) per kernel position, reduced over out- and in-channels -
+    including the reference's quirk that the UNSIGNED branch takes the minimum of |x| (ops.py:156), and a 3-D tensor."""
+    idx = 0
+    for shape in ((6, 4, 3, 3), (5, 3, 1, 1), (4, 6, 5), (8, 2, 7, 7)):
+        for signed, n_bits in ((True, 8), (False, 8), (True, 4), (False, 4)):
+            g = gen(7500 + idx)
+            x = torch.randn(shape, generator=g)
+            if idx % 3 == 2:
+                x = torch.relu(x) + 0.05
+            arrays = dict(x=x)
+            s, o = ops.get_qparams_tensor(x, "minmax_pixel", n_bits=n_bits, signed=signed)
+            arrays.update(scale=s, offset=o)
+            if not signed:
+                s, o = ops.get_qparams_tensor(x.clone(), "minmax_pixel", n_bits=n_bits, signed=signed, allow_offset=False)
+                arrays.update(scale_nooff=s, offset_nooff=o)
+            name = f"pixel{idx}"
+            put(name, **arrays)
+            CASES.append(dict(name=name, kind="minmax_pixel", shape=list(shape), signed=signed, n_bits=n_bits))
+            idx += 1
+
+
+def main_supplement2():
+    """Round 4: golden_v2.{npz,json} (golden_v1 and golden_v1_grad are not regenerated)."""
+    torch.manual_seed(SEED)
+    torch.set_num_threads(1)
+    case_lsq()
+    case_minmax_pixel()
+    np.savez_compressed(os.path.join(HERE, "golden_v2.npz"), **ARR)
+    with open(os.path.join(HERE, "golden_v2.json"), "w") as f:
+        json.dump(dict(seed=SEED, torch=torch.__version__, cases=CASES), f, indent=1, default=str)
+    print(f"{len(CASES)} cases, {len(ARR)} arrays (supplement 2)")
+
+
 def main():
     torch.manual_seed(SEED)
     torch.set_num_threads(1)
@@ -633,4 +716,9 @@ def main_supplement():
 
 
 if __name__ == "__main__":
-    main_supplement() if "--supplement" in sys.argv else main()
+    if "--supplement2" in sys.argv:
+        main_supplement2()
+    elif "--supplement" in sys.argv:
+        main_supplement()
+    else:
+        main()

@@ -69,3 +69,17 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_a_stale_library_override_is_reported_and_ignored():
+    """DLMCQ_LIBRARY alone must not swap the product library: it takes DLMCQ_LAB_TOOLS=1 as well, and then says so."""
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); from dlmc import _native as N; print(N.LIB_PATH)" % os.path.join(ROOT, "dlmc-quant_amd")
+    env = dict(os.environ, DLMCQ_LIBRARY="/nonexistent/libother.so")
+    env.pop("DLMCQ_LAB_TOOLS", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert r.stdout.strip().endswith(os.path.join("dlmc-quant_amd", "libdlmcq.so")) and "ignored" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, DLMCQ_LAB_TOOLS="1"), timeout=240)
+    assert r.returncode != 0 and "lab override: loading /nonexistent/libother.so" in r.stderr      # named, printed, and then a hard failure

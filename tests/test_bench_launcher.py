@@ -28,6 +28,10 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["config"]["global_batch"] == 4096 and d["config"]["parallelism"].startswith("dp2")
     assert "dry-run" in d["data"] and d["value"] == 0.0          # a dry line carries no measurement and says so
+    # what the collective library saw (the object a real N > 1 line carries: bench.collective_report)
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["world"] == 2 and c["ranks_seen"] == 2 and c["rccl_version"] is None
+    assert c["observer_allreduce_calls_timed"] == 54 and c["observer_allreduce_ms"] > 0 and c["steady_state_collectives_per_step"] == 0
 
 
 def test_world_size_mismatch_is_an_error_not_an_assert():

@@ -125,7 +125,10 @@ def test_resnet50_batch512_every_plan_node_against_the_oracle():
     torch.manual_seed(2333)
     model = merge_bn(W.resnet50().to(DEV).eval(), inplace=True, allow_missing=True)
     quantize_model(model, json.loads(json.dumps(FSPTQ)), None, quantization_type="FSPTQ", int8_gemm=True)
-    x = torch.relu(torch.randn(batch, 3, 224, 224, device=DEV)).contiguous(memory_format=torch.channels_last)
+    # the image is NCHW, as bench.py hands it over (the reference's loaders do): the first node's quantiser then runs its
+    # four-pixels-per-thread plane reader at full size; the channels_last form is checked against it below
+    x = torch.relu(torch.randn(batch, 3, 224, 224, device=DEV))
+    assert x.is_contiguous()
     recs = []
     with torch.no_grad():
         model(x)
@@ -209,6 +212,12 @@ def test_resnet50_batch512_every_plan_node_against_the_oracle():
                 if c is not None:
                     counts.append(c)
     _rate_check("resnet50", counts)
+    # the first node once more with the same image in channels_last memory (the other reader of the image quantiser): same bytes
+    stem_mod, stem_args, stem_out = next(r for r in recs if isinstance(r[0], StemLayer))
+    with torch.no_grad():
+        again = stem_mod(stem_args[0].contiguous(memory_format=torch.channels_last))
+    for a, b in zip(again, stem_out):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), "first node: NCHW and channels_last images disagree"
     assert beyond_2g == 0      # (layer1's fp32 tensors are 1.64 GB: byte offsets pass 2^30, not 2^31 - the next test does)
     print(f"checked {len(recs)} plan nodes x 6 windows; epilogue / kernel kinds seen: {sorted(kinds)}")
 

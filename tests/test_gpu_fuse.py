@@ -663,3 +663,47 @@ def test_eager_fused_calibrates_and_runs_like_the_model(name, family):
         want1, got1 = net(x * 0.7), fused(x * 0.7)
         assert torch.equal(want1.view(torch.int32), got1.view(torch.int32))
         assert torch.equal(twin(x * 0.7).view(torch.int32), got1.view(torch.int32))      # the wrappers themselves are untouched
+
+
+def test_eager_fused_keeps_its_promise_on_shortcuts_it_cannot_fuse():
+    """EagerFused promises `y == model(x)`: a broadcast shortcut (not the layer's output shape) and an in-place add INTO the shortcut
+    (`short += layer(x)`: the fused launch would not mutate `short`) must run layer, add and ReLU one by one - same bits, and the
+    in-place add still mutates what it mutates in the model."""
+    import copy
+    from dlmc.utils.fuse import EagerFused
+    from dlmc.utils.quantize import quantize_model
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Conv2d(64, 64, 1)
+            self.b = torch.nn.Conv2d(64, 64, 3, padding=1)
+            self.c = torch.nn.Conv2d(64, 64, 1)
+            self.pool = torch.nn.AvgPool2d(3, 1, 1)
+            self.relu = torch.nn.ReLU()
+
+        def forward(self, x):
+            y = self.relu(self.a(x) + x.mean(dim=(2, 3), keepdim=True))      # broadcast shortcut [N, 64, 1, 1]
+            idt = self.pool(y)
+            idt.add_(self.b(y))                                               # in-place add into the shortcut (`idt += ...` reaches torch.fx as a plain add)
+            z = self.relu(idt)
+            return self.relu(self.c(z) + z), idt                              # a shortcut the epilogue does take; idt as the model leaves it
+
+    cfg = {"weight": {"enable": True, "type": "minmax_channel", "args": {"n_bits": 8, "signed": True}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+           "exclude_layers": [], "override_options": []}
+    torch.manual_seed(7)
+    net = Net().to(DEV).eval()
+    quantize_model(net, cfg, None, "FSPTQ", int8_gemm=True)
+    twin = copy.deepcopy(net)
+    x = torch.relu(torch.randn(4, 64, 12, 12, device=DEV))
+    with torch.no_grad():
+        want = net(x)
+        fused = EagerFused(twin)
+        got = fused(x)
+        st = fused.last_states
+        assert st["a"] == "plain" and st.get("b", "plain") == "plain" and st["c"] == "fused", st
+        for g, w in zip(got, want):
+            assert torch.equal(g.view(torch.int32), w.view(torch.int32))
+        for g, w in zip(fused(x * 0.5), net(x * 0.5)):
+            assert torch.equal(g.view(torch.int32), w.view(torch.int32))

@@ -628,3 +628,79 @@ def test_block_reconstruction_stays_on_the_device():
         after = float((block(xin) - yout).pow(2).mean())
     print(f"block reconstruction (soft rounding): l2 {before:.5f} -> {after:.5f}")
     assert after < 0.9 * before
+
+
+def test_lsq_initialisation_against_the_reference(golden):
+    """`type: "LSQ"` (modules/base.py:84-85 input, :118-121 weight; LSQ_config.yaml, the QAT flow's default) through QConv2d /
+    QLinear on the GPU against golden_v2 (the reference's own forward).  The scale 2 * mean|x| / sqrt(Qp) is one HIP launch
+    (dlmcq_lsq_init_f32); its mean is summed in double precision in a fixed order, the reference's CPU run sums fp32 in ATen's
+    order, so the SCALE is compared to 2e-6 relative (stated tolerance; everything after the mean is the same fp32 chain with a
+    true division).  With the reference's scales loaded the fake-quantised operands are then compared bit for bit."""
+    cases = golden.of_kind("lsq")
+    assert len(cases) == 12
+    exact = 0
+    for c in cases:
+        net, cap = _quantized(c, golden)
+        q = net.layer
+        x, x2 = golden.get(c, "x").to(DEV), golden.get(c, "x2").to(DEV)
+        with torch.no_grad():
+            out = net(x)
+            for name in ("in_scale", "wt_scale"):
+                got, want = getattr(q, name).detach().cpu().reshape(-1), golden.get(c, name).reshape(-1)
+                torch.testing.assert_close(got, want, rtol=2e-6, atol=0, msg=lambda m: f"{c['name']}.{name}: {m}")
+                exact += int(torch.equal(got, want))
+            same_values(q.in_offset.reshape(-1), golden.get(c, "in_offset"), c["name"] + ".in_offset")
+            same_values(q.wt_offset.reshape(-1), golden.get(c, "wt_offset"), c["name"] + ".wt_offset")
+            assert float(q.in_init_state) == 1 and float(q.wt_init_state) == 1
+            # a scale that differs in its last bit moves every fake-quantised value by that much, and a value on a rounding tie by one step
+            step_in, step_wt = float(golden.get(c, "in_scale")), float(golden.get(c, "wt_scale"))
+            for got, want, step, what in ((cap.input, golden.get(c, "fq_input"), step_in, "fq_input"),
+                                          (cap.weight, golden.get(c, "fq_weight"), step_wt, "fq_weight")):
+                d = (got.cpu() - want).abs()
+                assert float(d.max()) <= step * 1.0001 and float((d > 1e-5 * want.abs() + 1e-9).float().mean()) <= 0.01, f"{c['name']}.{what}"
+            close(out, golden.get(c, "out"), c["name"] + ".out", rtol=1e-3, atol=2 * (step_in + step_wt))
+            # the reference's own scales in place: the operands bit for bit, on new data (frozen scales)
+            q.in_scale.copy_(golden.get(c, "in_scale").to(DEV))
+            q.wt_scale.copy_(golden.get(c, "wt_scale").to(DEV))
+            out2 = net(x2)
+            assert_bits_equal(cap.input, golden.get(c, "fq_input2"), c["name"] + ".fq_input2")
+            assert_bits_equal(cap.weight, golden.get(c, "fq_weight"), c["name"] + ".fq_weight (reference scale)")
+            close(out2, golden.get(c, "out2"), c["name"] + ".out2")
+        assert sorted(q.state_dict().keys()) == c["state_keys"]
+    print(f"LSQ scales bit-identical to the reference's: {exact} of {2 * len(cases)}")
+
+
+def test_lsq_init_kernel_shapes_and_errors():
+    """dlmcq_lsq_init_f32 on sizes around its vector width and grid (1, 3, 4, 255, 2^20 + 3 elements, a channels_last view) against
+    float64 arithmetic; argument checks."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for n in (1, 3, 4, 5, 255, 4096, (1 << 20) + 3):
+        x = torch.randn(n, device=DEV, generator=g) * 3
+        want = 2 * (x.double().abs().sum() / n).float() / torch.tensor(math.sqrt(127), dtype=torch.float32, device=DEV)
+        torch.testing.assert_close(K.lsq_init(x, 127).reshape(()), want, rtol=3e-7, atol=0)
+    x = torch.randn(8, 16, 14, 14, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(K.lsq_init(x, 7), K.lsq_init(x.contiguous(), 7), rtol=3e-7, atol=0)
+    one = torch.zeros(4, device=DEV)
+    assert N.lib.dlmcq_lsq_init_f32(N.ptr(one), N.ptr(one), 0, 1.0, N.ptr(one), 16384, None) == -1      # empty mean
+    assert N.lib.dlmcq_lsq_init_f32(N.ptr(one), N.ptr(one), 4, 1.0, None, 0, None) == -3                  # no scratch
+
+
+def test_minmax_pixel_against_the_reference(golden):
+    """ops.py:142-167 through get_qparams_tensor(qtype="minmax_pixel") on the GPU against golden_v2: bit for bit (max / min are
+    exact), the |x|-minimum of the unsigned branch (ops.py:156) included, 4-D and 3-D tensors, allow_offset=False."""
+    from dlmc.quantization.scalar import ops
+    cases = golden.of_kind("minmax_pixel")
+    assert len(cases) == 16
+    for c in cases:
+        x = golden.get(c, "x").to(DEV)
+        s, o = ops.get_qparams_tensor(x, "minmax_pixel", n_bits=c["n_bits"], signed=c["signed"])
+        want = golden.get(c, "scale")
+        assert list(s.shape) == list(want.shape)
+        assert_bits_equal(s, want, c["name"] + ".scale")
+        assert_bits_equal(o, golden.get(c, "offset"), c["name"] + ".offset")
+        if golden.has(c, "scale_nooff"):
+            s, o = ops.get_qparams_tensor(x, "minmax_pixel", n_bits=c["n_bits"], signed=c["signed"], allow_offset=False)
+            assert_bits_equal(s, golden.get(c, "scale_nooff"), c["name"] + ".scale_nooff")
+            assert_bits_equal(o, golden.get(c, "offset_nooff"), c["name"] + ".offset_nooff")

@@ -292,3 +292,52 @@ def test_output_aware_estimator(golden):
         assert_bits_equal(xq, golden.get(c, "fq_input"))
         s, o = O.l2norm_output(m, xq, m.weight.detach(), 4, True)
         torch.testing.assert_close(s.reshape(1), golden.get(c, "wt_scale"), rtol=1e-4, atol=0)
+
+
+def test_lsq_initialisation(golden):
+    """`type: "LSQ"` (modules/base.py:84-85,118-121; the QAT flow's default, LSQ_config.yaml): 2 * mean|x| / sqrt(Qp), then the
+    QBase forward with that scale - golden_v2, produced by the reference's own forward."""
+    cases = golden.of_kind("lsq")
+    assert len(cases) == 12
+    for c in cases:
+        m = _layer(c, golden)
+        ic, wc = c["qconfig"]["input"], c["qconfig"]["weight"]
+        ia, wa = ic["args"], wc["args"]
+        irng, wrng = O.qrange(ia["signed"], ia["n_bits"]), O.qrange(wa["signed"], wa["n_bits"])
+        x = golden.get(c, "x")
+        if ic["type"] == "LSQ":
+            s_in, o_in = O.lsq_init(x, irng[1]), torch.zeros(())
+        else:
+            s_in, o_in = O.minmax_tensor(x, ia["n_bits"], ia["signed"])
+        assert_bits_equal(s_in.reshape(1), golden.get(c, "in_scale"), c["name"] + ".in_scale")
+        assert_bits_equal(o_in.reshape(-1), golden.get(c, "in_offset"), c["name"] + ".in_offset")
+        xq, _ = O.fq_qbase(x, s_in.reshape(1), o_in, irng[0], irng[1], 1 / math.sqrt(x.numel() * irng[1]))[::-1]
+        assert_bits_equal(xq, golden.get(c, "fq_input"), c["name"] + ".fq_input")
+        # the weight's LSQ scale (base.py:118-121) is taken AFTER the input was fake-quantised, from the raw weight
+        w = m.weight.detach()
+        s_wt, o_wt = (O.lsq_init(w, wrng[1]), torch.zeros(())) if wc["type"] == "LSQ" else O.minmax_tensor(w, wa["n_bits"], wa["signed"])
+        assert_bits_equal(s_wt.reshape(1), golden.get(c, "wt_scale"), c["name"] + ".wt_scale")
+        xq_, wq, out = O.qbase_layer_forward(m, x, s_in.reshape(1), o_in, s_wt.reshape(1), o_wt, irng, wrng)
+        assert_bits_equal(xq_, golden.get(c, "fq_input"))
+        assert_bits_equal(wq, golden.get(c, "fq_weight"), c["name"] + ".fq_weight")
+        assert_out_close(out, golden.get(c, "out"), c["name"] + ".out")
+        xq2, _, out2 = O.qbase_layer_forward(m, golden.get(c, "x2"), s_in.reshape(1), o_in, s_wt.reshape(1), o_wt, irng, wrng)
+        assert_bits_equal(xq2, golden.get(c, "fq_input2"))
+        assert_out_close(out2, golden.get(c, "out2"))
+
+
+def test_minmax_pixel(golden):
+    """ops.py:142-167, with the reference's |x|-minimum in the unsigned branch."""
+    cases = golden.of_kind("minmax_pixel")
+    assert len(cases) == 16
+    for c in cases:
+        x = golden.get(c, "x")
+        s, o = O.minmax_pixel(x, c["n_bits"], c["signed"])
+        want = golden.get(c, "scale")
+        assert list(s.shape) == list(want.shape) == list(x.shape[2:])
+        assert_bits_equal(s, want, c["name"] + ".scale")
+        assert_bits_equal(o, golden.get(c, "offset"), c["name"] + ".offset")
+        if golden.has(c, "scale_nooff"):
+            s, o = O.minmax_pixel(x, c["n_bits"], c["signed"], allow_offset=False)
+            assert_bits_equal(s, golden.get(c, "scale_nooff"))
+            assert_bits_equal(o, golden.get(c, "offset_nooff"))

@@ -14,6 +14,7 @@ import torch  # noqa: E402
 
 if "--lab" in " ".join(sys.argv):
     os.environ["DLMCQ_LIBRARY"] = os.path.join(ROOT, "dlmc-quant_amd", "libdlmcq_lab.so")
+    os.environ["DLMCQ_LAB_TOOLS"] = "1"
 from dlmc import _native as N  # noqa: E402
 from dlmc.quantization.scalar import kernels as K  # noqa: E402
 

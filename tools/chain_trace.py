@@ -8,6 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dlmc-quant_amd")]
 os.environ["DLMCQ_LIBRARY"] = os.path.join(ROOT, "dlmc-quant_amd", "libdlmcq_lab.so")
+os.environ["DLMCQ_LAB_TOOLS"] = "1"
 import torch  # noqa: E402
 
 from dlmc import _native as N  # noqa: E402

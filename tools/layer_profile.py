@@ -44,7 +44,7 @@ with torch.no_grad():
 K.PROFILE.enabled = False
 per = len(K.PROFILE.records) // args.iters
 rows = {}
-for i, (tag, nbytes, a, b) in enumerate(K.PROFILE.records):
+for i, (tag, nbytes, a, b, _) in enumerate(K.PROFILE.records):
     rows.setdefault(i % per, [tag, nbytes, []])[2].append(a.elapsed_time(b) * 1e3)
 layers = shapes[:len(shapes) // args.iters]
 tot = {}

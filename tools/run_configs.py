@@ -43,7 +43,7 @@ def time_model(model, x, iters):
         dt = (time.perf_counter() - t0) / iters
         K.PROFILE.enabled = False
     fam = {}
-    for tag, nbytes, a, b in K.PROFILE.records:
+    for tag, nbytes, a, b, _ in K.PROFILE.records:
         f = fam.setdefault(tag, [0, 0.0])
         f[0] += nbytes
         f[1] += a.elapsed_time(b)
