@@ -71,6 +71,12 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
     const float* __restrict__ s_in, const float* __restrict__ zp_in, const float* __restrict__ s_w, HaloGeom g, int shift, ConvEpi ep,
     unsigned long long* __restrict__ trace) {
   constexpr bool STAMP = LAB == 1;
+  // LAB 9 / 10 / 11 (timing only, round 4): the workgroups that take a CU's SECOND slot in the first round start half / a quarter / a
+  // whole tile life late, so that the two workgroups of a CU are out of phase (one in its matrix-bound K loop, one in its vector-bound
+  // epilogue) - what a phase-shifted pair is worth before anything is built for it
+  if (LAB >= 9 && LAB <= 11 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int i = 0; i < (LAB == 9 ? 4 : LAB == 10 ? 2 : 8); ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const unsigned long long t_start = STAMP ? __builtin_readcyclecounter() : 0ull;
   constexpr int NT = NW * 64;               // threads
   constexpr int NBUF = 3;
@@ -474,6 +480,7 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
       switch (v) {
 #define DLMCQ_HALO_LAB(V) case V: hipLaunchKernelGGL((conv3x3_halo_i8_kernel<128, TM, 4, 1, 6, 2, 2, true, V>), DLMCQ_HALO_ARGS(4)); break
         DLMCQ_HALO_LAB(1); DLMCQ_HALO_LAB(2); DLMCQ_HALO_LAB(3); DLMCQ_HALO_LAB(4); DLMCQ_HALO_LAB(6); DLMCQ_HALO_LAB(7); DLMCQ_HALO_LAB(8);
+        DLMCQ_HALO_LAB(9); DLMCQ_HALO_LAB(10); DLMCQ_HALO_LAB(11);
 #undef DLMCQ_HALO_LAB
         default: return DLMCQ_EINVAL;
       }

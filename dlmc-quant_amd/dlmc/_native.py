@@ -74,6 +74,9 @@ SIGNATURES = {
                                                 _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
     "dlmcq_conv2d_dw_i8_nhwc": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32,
                                               _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
+    "dlmcq_dwpw_pack_table": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
+    "dlmcq_conv2d_dwpw_i8_nhwc": (ctypes.c_int, [_p, _p, _i32, _i32, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _i32, _i32, _i32, _f32,
+                                                _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _p]),
     "dlmcq_conv2d_i8_nhwc_dual": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                                 _i32, _i32, _i32, _i32,
                                                 _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32,

@@ -528,6 +528,67 @@ def conv2d_dw_i8(codes, wq, bias, in_scale, in_zp, w_scale, w_offset=None, strid
     return (out, out_codes) if emit is not None else out
 
 
+DWPW_WIDTHS = (128, 192, 512)      # pointwise output widths dlmcq_conv2d_dwpw_i8_nhwc is built for
+
+
+def dwpw_supported(c, k, h, w, stride, padding, ksize):
+    """Whether dlmcq_conv2d_dwpw_i8_nhwc takes a depthwise layer (c channels, ksize x ksize, stride, padding, input h x w) followed
+    by a pointwise layer to k channels."""
+    return ksize == 3 and stride == 1 and padding == 1 and c % 64 == 0 and k in DWPW_WIDTHS and w <= 61 and h >= 1
+
+
+def dwpw_table(wq, bias, in_scale, in_zp, w_scale, w_offset, x_unsigned=True):
+    """The depthwise layer's constants in the fused kernel's layout (dlmcq_dwpw_pack_table): int32 [C / 64, 64, 8]."""
+    N.require_gpu(wq)
+    r, s_, c = wq.shape
+    if (r, s_) != (3, 3) or c % 64:
+        raise ValueError("dwpw_table: 3 x 3 weights [3, 3, C], C % 64 == 0")
+    table = torch.empty((c // 64, 64, 8), dtype=torch.int32, device=wq.device)
+    ws = _f32c(w_scale.detach(), wq).reshape(-1)
+    wo = None if w_offset is None else _f32c(w_offset.detach(), wq).reshape(-1)
+    si = _f32c(in_scale.detach(), wq).reshape(-1)
+    zp = None if in_zp is None else _f32c(in_zp, wq).reshape(-1)
+    b = None if bias is None else bias.detach().contiguous()
+    N.check(N.lib.dlmcq_dwpw_pack_table(N.ptr(wq), N.ptr(b), N.ptr(si), N.ptr(zp), N.ptr(ws), N.ptr(wo), c, int(bool(x_unsigned)),
+                                        N.ptr(table), N.stream_ptr()))
+    return table
+
+
+def conv2d_dwpw_i8(codes, table, dw_asym, dw_bias, dw_relu, in_zp, emit, pw, relu=True, emit2=None):
+    """Depthwise 3x3 / 1 / 1 (+ ReLU + quantiser `emit`) and the pointwise 1x1 convolution `pw` on its codes (+ ReLU + the consumer's
+    quantiser `emit2`) in one kernel (dlmcq_conv2d_dwpw_i8_nhwc).  codes: (N, C, H, W) uint8 / int8 channels_last; table:
+    dwpw_table(...) of the depthwise layer; pw: dict with wq [K, 1, 1, C], wsum, bias, w_scale, optional w_offset and in_scale (the
+    scale the pointwise layer dequantises its input with).  Returns the codes (N, K, H, W)."""
+    _no_shift(emit, "conv2d_dwpw_i8")
+    _no_shift(emit2, "conv2d_dwpw_i8")
+    N.require_gpu(codes, table, pw["wq"])
+    if not codes.is_contiguous(memory_format=torch.channels_last):
+        codes = codes.contiguous(memory_format=torch.channels_last)
+    n, c, h, w_ = codes.shape
+    k = pw["wq"].shape[0]
+    if tuple(pw["wq"].shape[1:]) != (1, 1, c) or emit is None or emit2 is None or tuple(table.shape) != (c // 64, 64, 8):
+        raise ValueError("conv2d_dwpw_i8: a pointwise layer [K, 1, 1, C] on the depthwise layer's codes, both quantisers given")
+    out = torch.empty((n, k, h, w_), dtype=emit2.dtype, device=codes.device, memory_format=torch.channels_last)
+
+    def small(t):
+        return None if t is None else _f32c(t.detach() if hasattr(t, "detach") else t, codes).reshape(-1)
+
+    def vec(t):
+        t = _f32c(t.detach(), codes).reshape(-1)
+        return t.expand(k).contiguous() if t.numel() == 1 else t
+    zx, qs, qz, q2s, q2z = small(in_zp), small(emit.scale), small(emit.zero_point), small(emit2.scale), small(emit2.zero_point)
+    ws, wo, si = vec(pw["w_scale"]), (None if pw.get("w_offset") is None else vec(pw["w_offset"])), small(pw["in_scale"])
+    b = None if pw["bias"] is None else pw["bias"].detach().contiguous()
+    m = n * h * w_
+    nbytes = codes.numel() + table.numel() * 4 + pw["wq"].numel() + m * k
+    PROFILE.launch("conv_dwpw", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_dwpw_i8_nhwc(
+        N.ptr(codes), N.ptr(table), int(bool(dw_asym)), int(bool(dw_bias)), int(bool(dw_relu)), N.ptr(zx), n, h, w_, c,
+        int(codes.dtype == torch.uint8), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi, emit.form, emit.g, N.ptr(pw["wq"]), N.ptr(b),
+        N.ptr(pw["wsum"]), N.ptr(si), N.ptr(ws), N.ptr(wo), k, int(bool(relu)), N.ptr(out), N.ptr(q2s), N.ptr(q2z), emit2.lo, emit2.hi,
+        emit2.form, emit2.g, N.stream_ptr())), 2 * m * c * (9 + k))
+    return out
+
+
 def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True):
     """conv(a) + conv(b) in one kernel (dlmcq_conv2d_i8_nhwc_dual).  `a`, `b`: dicts with codes, wq, wsum, bias,
     in_scale, in_zp, w_scale and optional stride / padding / dilation; both must produce the same output shape.

@@ -409,6 +409,86 @@ class ChainInt8Layer(nn.Module):
         return K.conv2d_i8_dual_chain(mn.operand(x), sc.operand(y), nxt, relu3=b.relu, **kw)
 
 
+class DwPwInt8Layer(nn.Module):
+    """A depthwise 3x3 / stride 1 / pad 1 layer and the pointwise layer that alone reads its codes as ONE kernel
+    (csrc/conv_dwpw_i8.hip: the MobileOne / MobileNet unit; the wide code tensor between them stays in LDS).  Returns
+    `(None, codes)` like a codes-only Int8Layer; inputs the kernel is not built for run the two plan nodes one after the other."""
+
+    def __init__(self, dw, pw):
+        super().__init__()
+        self.dw, self.pw = dw, pw
+        self._tables = {}      # (elements of the input, unsigned?) -> the depthwise constants in the kernel's layout (QBase: s^ depends on numel)
+
+    def forward(self, x):
+        dw, pw = self.dw, self.pw
+        codes = dw._codes(x)
+        n, c, h, w = codes.shape
+        lay = dw.layer
+        if not K.dwpw_supported(c, pw.k_pad, h, w, lay.stride[0], lay.padding[0], lay.weight.shape[2]) or pw.c_pad != c:
+            return pw(dw(x)[1])
+        numel = dw._real_numel(codes)
+        key = (numel, codes.dtype == torch.uint8, dw.wq.data_ptr())
+        table = self._tables.get(key)
+        if table is None:
+            self._tables.clear()
+            table = self._tables[key] = K.dwpw_table(dw.wq, dw._bias(), dw._in_scale(numel), dw.act.zp, dw.w_scale, dw.w_off,
+                                                     x_unsigned=codes.dtype == torch.uint8)
+        emit = dw._emit_for(n, dw.k, h, w)                          # the depthwise output's quantiser = the pointwise layer's input quantiser
+        emit2 = pw._emit_for(n, pw.layer.weight.shape[0], h, w)
+        op = dict(wq=pw.wq, wsum=pw.wsum, bias=pw._bias(), w_scale=pw.w_scale, w_offset=pw.w_off, in_scale=pw._in_scale(n * h * w * pw.c))
+        out = K.conv2d_dwpw_i8(codes, table, dw.w_off is not None, dw._bias() is not None, dw.relu, dw.act.zp, emit, op, relu=pw.relu, emit2=emit2)
+        return pw._finish(None, out)
+
+
+def _dwpw_pass(gm, report):
+    """Depthwise 3x3 -> pointwise 1x1 (a MobileOne / MobileNet unit): replace the two plan nodes by one DwPwInt8Layer where the pointwise
+    layer is the only reader of the depthwise layer's codes and both emit codes only."""
+    graph = gm.graph
+    modules = dict(gm.named_modules())
+    count = 0
+    for nd in list(graph.nodes):
+        dw = modules.get(nd.target) if nd.op == "call_module" else None
+        if type(dw) is not DwInt8Layer or len(nd.args) != 1:
+            continue
+        lay = dw.layer
+        if not (tuple(lay.weight.shape[2:]) == (3, 3) and lay.stride[0] == 1 and lay.padding[0] == 1 and lay.dilation[0] == 1 and dw.pool is None and
+                dw.emit is not None and not dw.want_out and (dw.emit.lo, dw.emit.hi) == (0, 255) and not dw.emit_shift and dw.k_pad % 64 == 0):
+            continue
+        gets = {u.args[1]: u for u in nd.users if u.op == "call_function" and u.target is operator.getitem}
+        if len(gets) != len(nd.users) or 1 not in gets or (0 in gets and gets[0].users):
+            continue
+        g1 = gets[1]
+        if len(g1.users) != 1:
+            continue
+        npw = next(iter(g1.users))
+        pw = modules.get(npw.target) if npw.op == "call_module" else None
+        if type(pw) is not Int8Layer or npw.args != (g1,):
+            continue
+        pl = pw.layer
+        if not (pl.weight.dim() == 4 and tuple(pl.weight.shape[2:]) == (1, 1) and pl.stride[0] == 1 and pl.padding[0] == 0 and pw.pool is None and
+                pw.emit is not None and not pw.want_out and not pw.emit_shift and pw.c_pad == dw.k_pad and pw.k_pad in K.DWPW_WIDTHS):
+            continue
+        pgets = {u.args[1]: u for u in npw.users if u.op == "call_function" and u.target is operator.getitem}
+        if len(pgets) != len(npw.users) or (0 in pgets and pgets[0].users):
+            continue
+        name = f"_int8_dwpw_{count}"
+        count += 1
+        gm.add_module(name, DwPwInt8Layer(dw, pw))
+        with graph.inserting_after(npw):
+            nc = graph.call_module(name, args=nd.args)
+        with graph.inserting_after(nc):
+            codes = graph.call_function(operator.getitem, (nc, 1))
+        if 1 in pgets:
+            pgets[1].replace_all_uses_with(codes)
+        for n in list(pgets.values()) + [npw] + list(gets.values()) + [nd]:
+            graph.erase_node(n)
+    report.dwpw = count
+    if count:
+        graph.eliminate_dead_code()
+        graph.lint()
+        gm.recompile()
+
+
 def _pointwise(plan):
     """A plan node the chain kernel can take as either half: a plain 1x1 / stride 1 / unpadded int8 convolution."""
     lay = plan.layer
@@ -525,12 +605,14 @@ class FusionReport:
     def __init__(self):
         self.layers = self.relu = self.residual = self.emit = self.fp32_outputs = self.stem = self.pooled = self.dual = 0
         self.chained = 0      # block end + next block's 1x1 pairs running as one kernel
+        self.dwpw = 0         # depthwise 3x3 + pointwise 1x1 units running as one kernel
         self.skipped = []
 
     def __repr__(self):
         return (f"FusionReport(int8 layers={self.layers}, relu fused={self.relu}, residual fused={self.residual}, "
                 f"code-emitting={self.emit}, fp32 outputs kept={self.fp32_outputs}, stem layers={self.stem}, "
                 f"pools on codes={self.pooled}, dual (conv + shortcut conv) kernels={self.dual}, chained pairs={self.chained}, "
+                f"depthwise + pointwise units={self.dwpw}, "
                 f"not eligible={self.skipped})")
 
 
@@ -763,7 +845,7 @@ def _codes_from_blob(mod_name, blob, layer):
     return q.reshape(rec["shape"]).to(torch.int16)
 
 
-def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int4=True, weight_blob=None):
+def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int4=True, weight_blob=None, dwpw=False):
     """Return a `torch.fx.GraphModule` executing `model`'s calibrated quantised forward as the fused int8 plan.
     `pack_int4`: weight codes whose range fits 4 bits are stored packed and expanded by one launch per forward (PackedWeights4).
     `weight_blob`: an integer checkpoint (`dlmc.utils.export.export_quantized_state`) of the same model - the plan takes the
@@ -771,7 +853,11 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int
     Layers that are not eligible (grouped / 3-channel convs, non-integer zero points, RootQ, ...) keep running
     their own wrapper.  `model` must be on the GPU, in eval mode, already calibrated.  `dry_run=True` only takes the
     fusion decisions (graph + `fusion_report`, placeholder nodes): it needs no GPU and the result cannot be run.
-    `chain_pairs=False` keeps every block end and the 1x1 convolution behind it as two launches (A/B and tests)."""
+    `chain_pairs=False` keeps every block end and the 1x1 convolution behind it as two launches (A/B and tests).
+    `dwpw=True` runs every depthwise 3x3 / stride 1 + pointwise 1x1 unit (MobileOne, MobileNet) as ONE launch
+    (csrc/conv_dwpw_i8.hip: the code tensor between the two layers stays in LDS; bit-identical).  Off by default: at MobileOne-S1
+    W4A8, batch 1024, the unit takes 270 us either way at 28^2 and 14^2 (148 + 123 and 108 + 114 us as two launches) - both halves
+    are bound by their vector arithmetic (~24 instructions per depthwise element), which fusing does not remove."""
     if model.training:
         raise RuntimeError("fuse_inference: the plan is for inference - call model.eval() first")
     report = report if report is not None else FusionReport()
@@ -933,6 +1019,9 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int
     gm.recompile()
     if chain_pairs and not dry_run:
         _chain_pass(gm, report)
+        if dwpw:      # (off by default: measured no faster than the two launches - both halves of a MobileOne unit are bound by their
+            #            own vector arithmetic, not by the code tensor between them: LABNOTES round 4)
+            _dwpw_pass(gm, report)
     gm.packed_weights = _pack_plan_weights(gm) if (pack_int4 and not dry_run) else []
     gm.fusion_report = report
     return gm

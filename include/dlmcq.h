@@ -386,6 +386,30 @@ int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* out, const fl
                             int32_t q_hi, int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
 
 /*
+ * A MobileOne / MobileNet unit as ONE launch (round 4): depthwise 3x3 / stride 1 / pad 1 (+ ReLU + quantiser) followed by the
+ * pointwise 1x1 convolution that reads nothing but its codes (+ ReLU + the consumer's quantiser): dlmcq_conv2d_dw_i8_nhwc followed
+ * by dlmcq_conv2d_i8_nhwc_asym / _fused with codes-only output, same integers, same fp32 chains, same quantisers - bit-identical -
+ * but the wide code tensor between the two layers stays in LDS (csrc/conv_dwpw_i8.hip).
+ *   dlmcq_dwpw_pack_table   the depthwise layer's constants (w: int8 codes [9][C] tap-major, per-channel w_scale, optional w_offset
+ *                           and bias, the layer's input scale / zero point) -> `table`: C * 32 bytes, 16-byte aligned, C % 64 == 0.
+ *                           Made once per (layer, input scale): what conv_dw3_i8_kernel builds per workgroup.
+ *   dlmcq_conv2d_dwpw_i8_nhwc   x: NHWC codes [N][H][W][C] (uint8 if x_is_unsigned), W <= 61; (q_*): the depthwise output's
+ *                           quantiser = the pointwise layer's input quantiser, range [0, 255]; pw_in_scale: the scale the pointwise
+ *                           layer dequantises with (= q_scale, or its grad_scale value for QBase); w: int8 [K][C], K in {128, 192,
+ *                           512}, with wsum / w_scale / optional w_offset / bias [K]; codes: [N][H][W][K] under (q2_*).
+ */
+int dlmcq_dwpw_pack_table(const int8_t* w, const float* bias, const float* in_scale, const float* in_zero_point,
+                          const float* w_scale, const float* w_offset, int64_t C, int32_t x_is_unsigned, void* table,
+                          dlmcq_stream_t stream);
+int dlmcq_conv2d_dwpw_i8_nhwc(const void* x, const void* dw_table, int32_t dw_asym, int32_t dw_bias, int32_t dw_relu,
+                              const float* in_zero_point, int64_t N, int64_t H, int64_t W, int64_t C, int32_t x_is_unsigned,
+                              const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi, int32_t q_form,
+                              float q_ste_g, const int8_t* w, const float* bias, const int32_t* wsum, const float* pw_in_scale,
+                              const float* w_scale, const float* w_offset, int64_t K, int32_t relu, void* codes,
+                              const float* q2_scale, const float* q2_zero_point, int32_t q2_lo, int32_t q2_hi, int32_t q2_form,
+                              float q2_ste_g, dlmcq_stream_t stream);
+
+/*
  * Two convolutions into ONE output: out = conv(x, w) + conv(x2, w2), each dequantised with its own scales and bias
  * and summed in fp32 (one addition, as `out += identity` does it in a residual block whose shortcut is a
  * convolution), then the epilogue of dlmcq_conv2d_i8_nhwc_fused.  Both pairs must give the same [N, P, Q, K] output;

@@ -41,12 +41,19 @@ def test_mobileone_s1_w4a8_plan_node_by_node(family, batch, size, full):
     recs = []
     with torch.no_grad():
         want = net(x)                       # calibrates; the module path (fp32 convolutions of the fake-quantised operands)
+        # node by node on the plan bench.py times (every layer its own launch, its own hook); the same plan with its 17 stride-1
+        # depthwise + pointwise units as ONE kernel each (csrc/conv_dwpw_i8.hip; `dwpw=True`, not the default: measured no faster)
+        # must give the same bits
         plan = fuse_inference(net)
+        fused = fuse_inference(net, dwpw=True)
+        assert fused.fusion_report.dwpw == 17 and plan.fusion_report.dwpw == 0, fused.fusion_report
         rep = plan.fusion_report
         for m in plan.modules():
             if isinstance(m, (Int8Layer, StemLayer)):
                 m.register_forward_hook(lambda mod, args, out: recs.append((mod, args, out)))
         got = plan(x)
+        got_fused = fused(x)
+    assert torch.equal(got_fused.view(torch.int32), got.view(torch.int32)), "the plan with fused depthwise + pointwise units differs from the unfused plan"
     n_dw = sum(isinstance(r[0], DwInt8Layer) for r in recs)
     # the 3-channel first layer (matrix cores, with the weight-offset term for the asymmetric W4 weights), 21 units, the classifier
     assert n_dw == 21 and len(recs) == 1 + 21 + 21 + 1 and isinstance(recs[0][0], StemLayer), (n_dw, len(recs), rep)
@@ -177,3 +184,50 @@ def test_plan_holds_packed_int4_weights_and_loads_the_integer_checkpoint():
     with torch.no_grad():
         r18(torch.relu(torch.randn(2, 3, 64, 64, device=DEV)))
         assert fuse_inference(r18).packed_weights == []
+
+
+@pytest.mark.parametrize("n,c,k,h,w,asym,zp", [(2, 64, 128, 9, 9, True, 4.0), (3, 128, 128, 56, 56, True, 0.0), (5, 192, 192, 28, 28, True, 3.0),
+                                            (4, 512, 512, 14, 14, True, 0.0), (1, 192, 512, 7, 5, False, 2.0), (7, 64, 192, 1, 1, True, 0.0),
+                                            (2, 256, 192, 3, 61, True, 1.0), (9, 128, 512, 2, 7, False, 0.0)])
+def test_depthwise_plus_pointwise_kernel_matches_the_two_launches(n, c, k, h, w, asym, zp):
+    """dlmcq_conv2d_dwpw_i8_nhwc (one launch: depthwise 3x3 / 1 / 1 + ReLU + quantiser, then pointwise 1x1 + ReLU + quantiser) against
+    dlmcq_conv2d_dw_i8_nhwc followed by dlmcq_conv2d_i8_nhwc_asym / _fused: the same bytes.  Shapes: all three widths, the widest
+    image the kernel takes (61), images smaller than a tile, tiles crossing images, a partial last tile, symmetric and asymmetric
+    weights on both layers, a non-zero zero point on the depthwise input (border code) and QBASE / ZEROPOINT quantisers."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator(device=DEV).manual_seed(n * 1000 + c + k + h)
+    codes = torch.randint(0, 256, (n, c, h, w), generator=g, device=DEV, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+    wdw = torch.randint(0, 16, (3, 3, c), generator=g, device=DEV).to(torch.int8)
+    s_dw = torch.rand(c, generator=g, device=DEV) * 0.02 + 0.001
+    o_dw = torch.randn(c, generator=g, device=DEV) * 0.05 if asym else None
+    b_dw = torch.randn(c, generator=g, device=DEV) * 0.3
+    s_in, zpt = torch.tensor([0.013], device=DEV), torch.tensor([zp], device=DEV)
+    wpw = torch.randint(-8 if not asym else 0, 8 if not asym else 16, (k, 1, 1, c), generator=g, device=DEV).to(torch.int8)
+    pw = dict(wq=wpw, wsum=wpw.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous(), bias=torch.randn(k, generator=g, device=DEV),
+              w_scale=torch.rand(k, generator=g, device=DEV) * 0.01 + 0.0005, w_offset=(torch.randn(k, generator=g, device=DEV) * 0.01 if asym else None))
+    form = N.FORM_QBASE if asym else N.FORM_ZEROPOINT
+    emit = K.EmitCodes(torch.tensor([0.021], device=DEV), torch.zeros(1, device=DEV), 0, 255, form, g=1e-3 if asym else 0.0)
+    emit2 = K.EmitCodes(torch.tensor([0.05], device=DEV), torch.zeros(1, device=DEV), 0, 255, form, g=2e-3 if asym else 0.0)
+    pw_in = torch.tensor([0.021], device=DEV)
+    _, mid = K.conv2d_dw_i8(codes, wdw, b_dw, s_in, zpt, s_dw, o_dw, stride=1, padding=1, relu=True, emit=emit, want_out=False)
+    _, want = K.conv2d_i8(mid, pw["wq"], pw["wsum"], pw["bias"], pw_in, emit.zero_point, pw["w_scale"], relu=True, emit=emit2, want_out=False,
+                          w_offset=pw["w_offset"])
+    assert K.dwpw_supported(c, k, h, w, 1, 1, 3)
+    table = K.dwpw_table(wdw, b_dw, s_in, zpt, s_dw, o_dw)
+    got = K.conv2d_dwpw_i8(codes, table, asym, True, True, zpt, emit, dict(pw, in_scale=pw_in), relu=True, emit2=emit2)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    bad = (got != want)
+    assert not bool(bad.any()), f"{int(bad.sum())} of {bad.numel()} codes differ, first at {bad.nonzero()[:4].tolist()}"
+
+
+def test_depthwise_plus_pointwise_argument_checks():
+    from dlmc import _native as N
+    one = torch.zeros(64, device=DEV)
+    p = N.ptr(one)
+    f = N.lib.dlmcq_conv2d_dwpw_i8_nhwc
+    args = lambda K_, W_, C_=64, lo=0: (p, p, 1, 1, 1, p, 1, 4, W_, C_, 1, p, p, lo, 255, 2, 0.0, p, p, p, p, p, p, K_, 1, p, p, p, 0, 255, 2, 0.0, None)   # noqa: E731
+    assert f(*args(256, 8)) == -1          # a width the kernel is not built for
+    assert f(*args(192, 63)) == -1         # an image wider than its halo buffers (W + 1 > 63)
+    assert f(*args(192, 8, 96)) == -1      # channels not a multiple of 64
+    assert f(*args(192, 8, 64, -128)) == -1   # the matrix step reads unsigned bytes

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 import workloads as W  # noqa: E402
 from bench import QCFG  # noqa: E402
-from dlmc.utils.fuse import ChainInt8Layer, DualInt8Layer, _PlanLayer as Int8Layer, fuse_inference  # noqa: E402
+from dlmc.utils.fuse import ChainInt8Layer, DualInt8Layer, DwPwInt8Layer, _PlanLayer as Int8Layer, fuse_inference  # noqa: E402
 from dlmc.utils.merge_bn import merge_bn  # noqa: E402
 from dlmc.utils.quantize import quantize_model  # noqa: E402
 
@@ -51,8 +51,11 @@ with torch.no_grad():
         inner |= {id(d.a), id(d.b)}
     for c in chains:
         inner |= {id(c.a), id(c.b), id(c.main), id(c.short)}
+    for p_ in plan.modules():
+        if isinstance(p_, DwPwInt8Layer):
+            inner |= {id(p_.dw), id(p_.pw)}
     for m in plan.modules():
-        if isinstance(m, (DualInt8Layer, ChainInt8Layer)) or (isinstance(m, Int8Layer) and id(m) not in inner):
+        if isinstance(m, (DualInt8Layer, ChainInt8Layer, DwPwInt8Layer)) or (isinstance(m, Int8Layer) and id(m) not in inner):
             m.register_forward_pre_hook(pre)
             m.register_forward_hook(post)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -65,6 +68,15 @@ tot = 0.0
 for mod, args, out, s, e in recs:
     us = s.elapsed_time(e) * 1e3
     tot += us
+    if isinstance(mod, DwPwInt8Layer):
+        xin, o = args[0], out[1]
+        wd, wp = mod.dw.layer.weight, mod.pw.layer.weight
+        m_ = o.numel() // o.shape[1]
+        macs = m_ * (wd.shape[0] * 9 + wp.numel())
+        nb = xin.numel() + o.numel() + wd.numel() + wp.numel()
+        print(f"{us:8.1f} us  DWPW in {str(tuple(xin.shape)):20s} dw {str(tuple(wd.shape)):16s} -> pw {str(tuple(wp.shape)):18s} relu     codes  "
+              f"{2 * macs / us / 1e6:6.0f} TOP/s {nb / us / 1e3:6.0f} GB/s")
+        continue
     if isinstance(mod, ChainInt8Layer):
         w1, w3 = mod.main.layer.weight, mod.b.layer.weight
         o = out[2]
