@@ -1027,6 +1027,21 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int
     return gm
 
 
+_STREAM_POOL = {}
+
+
+def _plan_streams(device, n):
+    """The side streams of every StreamedPlan on a device come from ONE pool: the runtime maps streams onto a few hardware queues,
+    and a second plan's fresh streams can land on queues the first plan's already occupy - its shares then run one after the other
+    (RepVGG-A1 behind ResNet-50 in one process: 2.28 ms per step on fresh streams, 1.85 on the shared ones = what it takes alone)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    pool = _STREAM_POOL.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 class StreamedPlan:
     """Run a frozen plan on `n_streams` HIP streams, each taking a contiguous share of the batch.
 
@@ -1055,7 +1070,7 @@ class StreamedPlan:
         if self.n == 1 or x.shape[0] < self.n:
             return self.plan(x)
         if self.streams is None:
-            self.streams = [torch.cuda.Stream(device=x.device) for _ in range(self.n)]
+            self.streams = _plan_streams(x.device, self.n)
         cur = torch.cuda.current_stream(x.device)
         parts = x.chunk(self.n, dim=0)
         outs = [None] * len(parts)

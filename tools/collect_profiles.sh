@@ -28,6 +28,8 @@ bash tools/pmc_layer.sh "gpurun_out/prof_$R/pmc_c4_halo" c4 128:5 > /dev/null 2>
 python3 tools/first_batch_probe.py > "$OUT/first_batch_probe.txt" 2>&1
 python3 tools/conv_lab.py --knobs 128:1,64:1,128:0,64:0,128:5,64:5 > "$OUT/conv_lab_resnet50_layers.txt" 2>&1
 python3 tools/chain_lab.py --rows 64 > "$OUT/chain_lab_resnet50_pairs.txt" 2>&1
+# where the chain kernel's vector-memory instructions wait: SQ / TA / TCP / TCC / TD counter passes (round 4)
+bash tools/pmc_chain_mem.sh "gpurun_out/prof_$R/pmc_chain_mem" s3,s2t,s1,s2 > /dev/null 2>&1 && cp "$OUT/pmc_chain_mem/summary.json" "$OUT/pmc_chain_kernel_sq_ta_tcp_tcc.json" || echo "pmc chain failed"
 python3 tools/chain_trace.py 512 64 56 256 64 > "$OUT/chain_trace_64_256_64_at_56.txt" 2>&1
 python3 tools/chain_trace.py 512 256 14 1024 256 > "$OUT/chain_trace_256_1024_256_at_14.txt" 2>&1
 python3 tools/conv_trace.py 512 256 14 256 3 > "$OUT/conv_trace_3x3_256_14.txt" 2>&1
