@@ -95,9 +95,15 @@ __device__ __forceinline__ void quad_transpose(float& x0, float& x1, float& x2, 
 constexpr int CHAIN_WGS(int c1, int kb) { return c1 + kb <= 256 ? 3 : 2; }
 constexpr int CH_BIG = 0x7fff0000;   // a byte offset beyond every buffer this kernel accepts (< 2^31 - 64 KiB)
 
-template <int C1, int KB, int C2 = 0>
+// FL (round 4): what the first epilogue does, known at compile time - bit 0: ReLU, bit 1: the fp32 output is stored; -1: both read
+// from the arguments at run time (the general form; the plan's launches are all ReLU ones).  A run-time flag is a uniform branch per
+// group of 4 values - five per group with the quantiser's, each a bubble in a wave's issue and a basic-block boundary the scheduler
+// cannot move work across.
+template <int C1, int KB, int C2 = 0, int FL = -1>
 __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_kernel(ChainArgs a, ConvEpi ep1, ConvEpi ep2) {
   constexpr bool DUALH = C2 > 0;         // the shortcut is a second convolution (no fp32 shortcut tensor)
+  const bool relu1 = FL < 0 ? ep1.relu != 0 : (FL & 1) != 0;
+  const bool out1 = FL < 0 ? a.out != nullptr : (FL & 2) != 0;
   constexpr int S1 = C1 / 64;            // K steps of GEMM 1
   constexpr int S2 = C2 / 64;            // K steps of the shortcut convolution
   constexpr int U3 = KB / 64;            // 64-row units of a W3 chunk = accumulator slabs of GEMM 2 per wave (KB/2 columns)
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 #pragma unroll
   for (int j = 0; j < 4; ++j) tw[j] = (4 * hsel + j) * 32 + (LDST2 ? l31 : ((l31 & 3) | ((l31 & ~3) ^ ((4 * hsel + j) * 4))));
   const int trd = LDST2 ? rsel * 32 + 4 * q4 : (4 * hsel + b4) * 32 + ((4 * q4) ^ ((4 * hsel + b4) * 4));   // (form 2: 8 lanes read one row = all 32 banks: no swizzle needed)
-  const int nst = (a.out ? 4 : 0) + (a.codes ? 1 : 0);   // stores per wave per chunk
+  const int nst = (out1 ? 4 : 0) + (a.codes ? 1 : 0);   // stores per wave per chunk
 
   // ---- DMA sources.  A wave-instruction lands 16 rows x 64 B; row r of a unit keeps its 16-byte segments XOR-swizzled ----
   const int lrow = lane >> 2, pslot = lane & 3;
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   ConvEpi e1 = ep1;
   e1.codes = reinterpret_cast<uint8_t*>(uintptr_t(1));   // the quantiser is always needed (GEMM 2 reads its codes)
   const EpiQuant eq1(e1);
+  __builtin_assume(!eq1.sgn);                            // (the range is [0, 255]: chain_launch refuses anything else)
 
   i32x16 acc2[U3];
 #pragma unroll
@@ -385,29 +392,49 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
       v[i] = dequant1(acc[i], mult, bv);
       if constexpr (DUALH) v[i] = v[i] + extra[DUALH ? i : 0];     // `out += identity`, the identity being a convolution
     }
+    // GP groups of 8 rows share ONE tie branch of the quantiser (code4n): with the flags above known at compile time that branch is the
+    // only basic-block boundary left in the epilogue, and the scheduler can run a group's LDS round trip under its neighbour's arithmetic
+#ifndef DLMCQ_CHAIN_GP
+#define DLMCQ_CHAIN_GP 4
+#endif
+    // (the two instantiations that sit at the 168 registers of three workgroups per CU keep the branch per group: more spills otherwise)
+    constexpr bool TIGHT = C2 == 0 && ((C1 == 64 && KB == 128) || (C1 == 128 && KB == 128));
+    constexpr int GP = (FL < 0 || TIGHT) ? 1 : DLMCQ_CHAIN_GP;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 y;
-      if constexpr (LDST) {
+    for (int g0 = 0; g0 < 4; g0 += GP) {
+      f32x4 y[GP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tstage[tw[j]] = v[4 * g + j];
-        // (the read takes what OTHER lanes of this wave wrote: LDS operations of a wave execute in order, and the compiler must
-        //  keep them in this order - a memory clobber between the writes and the read, and after the read, costs no instruction)
-        asm volatile("" ::: "memory");
-        y = *reinterpret_cast<const f32x4*>(tstage + trd);
-        asm volatile("" ::: "memory");
-      } else {
-        quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
-        y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      for (int k = 0; k < GP; ++k) {
+        const int g = g0 + k;
+        if constexpr (LDST) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tstage[tw[j]] = v[4 * g + j];
+          // (the read takes what OTHER lanes of this wave wrote: LDS operations of a wave execute in order, and the compiler must
+          //  keep them in this order - a memory clobber between the writes and the read, and after the read, costs no instruction)
+          asm volatile("" ::: "memory");
+          y[k] = *reinterpret_cast<const f32x4*>(tstage + trd);
+          asm volatile("" ::: "memory");
+        } else {
+          quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], b0, b1);
+          y[k] = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        }
+        if constexpr (!DUALH) y[k] = y[k] + res[P][g];
+        if (relu1) y[k] = relu4_nan(y[k]);
+        if (out1) bstore16(y[k], fo[g] + n * cstep, r_out);
       }
-      if constexpr (!DUALH) y = y + res[P][g];
-      if (ep1.relu) y = relu4_nan(y);
-      const int off = fo[g] + n * cstep;
-      if (a.out) bstore16(y, off, r_out);
-      const uint32_t c = eq1.code4(y);
-      const int R = wr * 32 + 8 * g + rsel;
-      *reinterpret_cast<uint32_t*>(ctile + R * 64 + (((wc * 2 + (q4 >> 2)) ^ ((R >> 2) & 3)) << 4) + (q4 & 3) * 4) = c;
-      CHAIN_FINE(1 + g);
+      uint32_t c[GP];
+      if constexpr (GP == 1) {
+        c[0] = eq1.code4(y[0]);
+      } else {
+        bool un[GP];
+        eq1.code4n(y, c, un);
+      }
+#pragma unroll
+      for (int k = 0; k < GP; ++k) {
+        const int R = wr * 32 + 8 * (g0 + k) + rsel;
+        *reinterpret_cast<uint32_t*>(ctile + R * 64 + (((wc * 2 + (q4 >> 2)) ^ ((R >> 2) & 3)) << 4) + (q4 & 3) * 4) = c[k];
+        CHAIN_FINE(1 + g0 + k);
+      }
     }
     CHAIN_STAMP();   // 3 + 3n: GEMM 1 + epilogue 1 issued
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the 64 x 64 code tile is complete
@@ -512,18 +539,27 @@ static int chain_launch(ChainArgs& a, int64_t M, int64_t C, int64_t K, int64_t C
 #ifdef DLMCQ_LAB
   dyn = (g_chain_lab & 128 ? 40960 : 0) + (g_chain_lab & 256 ? 81920 : 0);   // timing only: unused dynamic LDS = fewer workgroups per CU
 #endif
+  // the plan's launches end their first layer with a ReLU: those get the instantiation that knows its flags at compile time
+  const int fl = relu ? (a.out ? 3 : 1) : -1;
+#define DLMCQ_CHAIN_GO(...)                                                                                          \
+  do {                                                                                                               \
+    if (fl == 3) hipLaunchKernelGGL((conv_chain_i8_kernel<__VA_ARGS__, 3>), grid, block, dyn, st, a, ep1, ep2);       \
+    else if (fl == 1) hipLaunchKernelGGL((conv_chain_i8_kernel<__VA_ARGS__, 1>), grid, block, dyn, st, a, ep1, ep2);  \
+    else hipLaunchKernelGGL((conv_chain_i8_kernel<__VA_ARGS__, -1>), grid, block, dyn, st, a, ep1, ep2);              \
+  } while (0)
   if (C2 == 0) {
-    if (C == 64 && K2 == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 64>), grid, block, dyn, st, a, ep1, ep2);
-    else if (C == 64 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 128>), grid, block, dyn, st, a, ep1, ep2);
-    else if (C == 128 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 128>), grid, block, dyn, st, a, ep1, ep2);
-    else if (C == 128 && K2 == 256) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 256>), grid, block, dyn, st, a, ep1, ep2);
-    else if (C == 256 && K2 == 256) hipLaunchKernelGGL((conv_chain_i8_kernel<256, 256>), grid, block, dyn, st, a, ep1, ep2);
+    if (C == 64 && K2 == 64) DLMCQ_CHAIN_GO(64, 64, 0);
+    else if (C == 64 && K2 == 128) DLMCQ_CHAIN_GO(64, 128, 0);
+    else if (C == 128 && K2 == 128) DLMCQ_CHAIN_GO(128, 128, 0);
+    else if (C == 128 && K2 == 256) DLMCQ_CHAIN_GO(128, 256, 0);
+    else if (C == 256 && K2 == 256) DLMCQ_CHAIN_GO(256, 256, 0);
     else return DLMCQ_EINVAL;
   } else {
-    if (C == 64 && C2 == 64 && K2 == 64) hipLaunchKernelGGL((conv_chain_i8_kernel<64, 64, 64>), grid, block, dyn, st, a, ep1, ep2);
-    else if (C == 128 && C2 == 256 && K2 == 128) hipLaunchKernelGGL((conv_chain_i8_kernel<128, 128, 256>), grid, block, dyn, st, a, ep1, ep2);
+    if (C == 64 && C2 == 64 && K2 == 64) DLMCQ_CHAIN_GO(64, 64, 64);
+    else if (C == 128 && C2 == 256 && K2 == 128) DLMCQ_CHAIN_GO(128, 128, 256);
     else return DLMCQ_EINVAL;
   }
+#undef DLMCQ_CHAIN_GO
   return launch_status();
 }
 
