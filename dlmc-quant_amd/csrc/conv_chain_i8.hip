@@ -58,24 +58,6 @@ struct ChainArgs {
   unsigned long long* trace;   // lab builds: 64 clock-stamp slots per workgroup (null: none)
 };
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ v4i make_rsrc(const void* p, uint32_t bytes) {
-  const uint64_t a = (uint64_t)p;
-  return v4i{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
-__device__ __forceinline__ void bload16(f32x4& dst, int voff, const v4i& rsrc) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
-}
-// (a store of more than 8 bytes reads its data registers late: gfx940+ needs TWO wait states before a VALU instruction may
-//  overwrite them, and the hazard recogniser does not see inside inline asm - with one, the last quad of every 16 lanes
-//  can store the NEXT value of a dword)
-__device__ __forceinline__ void bstore16(const f32x4& v, int voff, const v4i& rsrc) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
-}
-__device__ __forceinline__ void bstore16i(const i32x4& v, int voff, const v4i& rsrc) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
-}
 template <int CTRL>
 __device__ __forceinline__ float quad_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));   // (every lane reads a live lane: no `old` value to initialise)

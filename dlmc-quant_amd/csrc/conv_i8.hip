@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
 #endif
   // ring depth: 3 slots (two K steps in flight); A/B hook for the 128-wide A-direct swapped kernel, whose LDS and registers leave room for more
   constexpr int BM = CV_BM, BK = CV_BK, NBUF = (SWAP && BN == 128 && ADIR && !ASYM) ? DLMCQ_NB_SWAP128 : 3, PF = NBUF - 1;
-  // LAB (lab library only): 1 = clock stamps; 2 = no A loads, 3 = no B loads, 4 = no MFMAs, 5 = all lanes load one A address
+  // LAB (lab library only): 1 = clock stamps; 2 = no A loads, 3 = no B loads, 4 = no MFMAs, 5 = all lanes load one A address,
+  // 6 = swapped epilogue without its arithmetic (the accumulators' low bytes are stored), 7 = no epilogue at all
   // (what-bounds-the-step experiments: results are garbage, only the time means something)
   constexpr bool STAMP = LAB == 1;
   constexpr int TILE_A = ADIR ? 0 : BM * BK, TILE_B = BN * BK, TILE = TILE_A + TILE_B;
@@ -389,9 +390,27 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
       s0 += (shift - zpi) * (g.R * g.S * g.C);
       s0f = (float)s0;
     }
+    if constexpr (LAB == 7) {
+      int any = 0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) any |= acc[j][i];
+      if (any == 0x7fffffff) ep.codes[0] = 1;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int cb = j * 32 + hsel * 16;
+      if constexpr (LAB == 6) {
+        uint32_t wl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          wl[q] = (uint32_t)(acc[j][4 * q] & 0xff) | ((uint32_t)(acc[j][4 * q + 1] & 0xff) << 8) | ((uint32_t)(acc[j][4 * q + 2] & 0xff) << 16) |
+                  ((uint32_t)acc[j][4 * q + 3] << 24);
+        *reinterpret_cast<i32x4*>(stg + l31 * SROW + cb) = i32x4{(int)wl[0], (int)wl[1], (int)wl[2], (int)wl[3]};
+        continue;
+      }
       f32x4 y[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -672,6 +691,8 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   // ... and widths of 192, 576, ... (no multiple of 128) 192-wide ones - codes-only layers with the swapped epilogue (MobileOne-S1's
   // 192 -> 192 layers at 28^2: one tile column fewer, a third fewer re-reads of the activations)
   if (!forced && ep.w_off && plan.bn == 64 && K % 192 == 0 && plan.swap && ep.codes && !out && !ep.residual && aligned16(ep.codes)) plan.bn = 192;
+  if (plan.halo && conv_pw_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
+    return conv_pw_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, shift, ep, st);
   if (plan.halo && conv3x3_halo_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
     return conv3x3_halo_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st);
   // 256-wide tiles exist for the swapped codes-only layers only (one third fewer operand bytes per MAC, two workgroups per CU)
@@ -910,6 +931,38 @@ extern "C" int dlmcq_x_conv2d_i8_tuned(const void* x, const int8_t* w, float* ou
     return conv3x3_halo_launch(reinterpret_cast<const int8_t*>(x), w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K,
                                stride, x_is_unsigned ? 128 : 0, e2, reinterpret_cast<hipStream_t>(stream), -pp_wps - 100,
                                const_cast<float*>(residual));
+  }
+  if (pp_wps <= -20 && pp_wps > -100) {   // ... of the swapped asymmetric kernels (LAB = -pp_wps - 20, 0 = as built; `bias` doubles as the weight offsets)
+    const int64_t P = (H + 2 * pad - dilation * (R - 1) - 1) / stride + 1, Q = (W + 2 * pad - dilation * (S - 1) - 1) / stride + 1;
+    if (C % CV_BK || K % bn || (bn != 128 && bn != 192) || P < 1 || Q < 1 || N * P * Q >= (1ll << 31) || !ep.codes || out) return DLMCQ_EINVAL;
+    ConvGeom g;
+    g.N = (int)N; g.H = (int)H; g.W = (int)W; g.C = (int)C; g.K = (int)K; g.R = (int)R; g.S = (int)S;
+    g.stride = stride; g.pad = pad; g.dil = dilation; g.P = (int)P; g.Q = (int)Q; g.M = N * P * Q;
+    g.qdiv = make_fastdiv((uint32_t)Q);
+    g.pdiv = make_fastdiv((uint32_t)P);
+    g.nblk_m = (int)((g.M + CV_BM - 1) / CV_BM);
+    g.nblk_n = (int)(K / bn);
+    const dim3 grid((uint32_t)((int64_t)g.nblk_m * g.nblk_n));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int8_t* xx = reinterpret_cast<const int8_t*>(x);
+    const int shift = x_is_unsigned ? 128 : 0;
+    ConvEpi e2 = ep;
+    e2.residual = nullptr;
+    e2.w_off = bias;
+#define DLMCQ_LABK(B, V) hipLaunchKernelGGL((conv_i8_mfma_kernel<B, false, true, true, V, true>), grid, dim3(256), 0, st, xx, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, e2, ConvSeg2{})
+#define DLMCQ_LABB(V) if (bn == 128) DLMCQ_LABK(128, V); else DLMCQ_LABK(192, V)
+    switch (-pp_wps - 20) {
+      case 0: DLMCQ_LABB(0); break;
+      case 2: DLMCQ_LABB(2); break;
+      case 3: DLMCQ_LABB(3); break;
+      case 4: DLMCQ_LABB(4); break;
+      case 6: DLMCQ_LABB(6); break;
+      case 7: DLMCQ_LABB(7); break;
+      default: return DLMCQ_EINVAL;
+    }
+#undef DLMCQ_LABB
+#undef DLMCQ_LABK
+    return launch_status();
   }
   if (pp_wps < 0) {   // what-bounds-the-step variants of the 128-wide direct-A kernel (LAB = -pp_wps)
     const int64_t P = (H + 2 * pad - dilation * (R - 1) - 1) / stride + 1, Q = (W + 2 * pad - dilation * (S - 1) - 1) / stride + 1;

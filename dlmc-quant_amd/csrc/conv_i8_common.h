@@ -61,12 +61,46 @@ __device__ __forceinline__ void gload16(i32x4& dst, const int8_t* p) {
   asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
 }
 
+// Buffer-addressed 16-byte accesses the compiler does not know about (no s_waitcnt is generated for them: the caller counts vmcnt).
+// A byte offset beyond the resource's size makes a load return zeros and a store vanish, so a lane outside its tile still ISSUES the
+// instruction: every wave issues the same number of vector-memory operations, which counted waits rely on.
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4i make_rsrc(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  return v4i{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void bload16(f32x4& dst, int voff, const v4i& rsrc) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void bload16i(i32x4& dst, int voff, const v4i& rsrc) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(dst) : "v"(voff), "s"(rsrc), "n"(OFF) : "memory");
+}
+// (a store of more than 8 bytes reads its data registers late: gfx940+ needs TWO wait states before a VALU instruction may
+//  overwrite them, and the hazard recogniser does not see inside inline asm - with one, the last quad of every 16 lanes
+//  can store the NEXT value of a dword)
+__device__ __forceinline__ void bstore16(const f32x4& v, int voff, const v4i& rsrc) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void bstore16i(const i32x4& v, int voff, const v4i& rsrc) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+constexpr int BUF_BIG = 0x7fff0000;   // a byte offset beyond every buffer these kernels accept (< 2^31 - 64 KiB)
+
 // conv3x3_i8.hip: the halo-tile kernel for 3x3 / stride 1 or 2 / pad 1 layers that emit only their consumer's codes
 bool conv3x3_halo_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
                           int32_t dilation, const ConvEpi& ep, const float* out, bool dual);
 int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, const int32_t* wsum, const float* in_scale,
                         const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
                         int32_t stride, int shift, const ConvEpi& ep, hipStream_t st, int lab = 0, void* lab_trace = nullptr);
+
+// conv_pw_i8.hip: pointwise codes-to-codes layers with the weights resident in LDS (MobileOne's 1x1 layers)
+bool conv_pw_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
+                     int32_t dilation, const ConvEpi& ep, const float* out, bool dual);
+int conv_pw_launch(const int8_t* x, const int8_t* w, const float* bias, const int32_t* wsum, const float* in_scale,
+                   const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int shift,
+                   const ConvEpi& ep, hipStream_t st);
 
 // conv_stem_pool7_i8.hip: the ResNet first layer (7x7 / 2 + ReLU + 3x3 / 2 max-pool + quantiser) with the pooling in registers
 bool stem_pool7_applies(int64_t Hp, int64_t Wp, int64_t K, int64_t R, int64_t S, int32_t stride, const float* out, const void* codes);
