@@ -7,6 +7,7 @@ namespace dlmcq {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // What an int8 kernel does with a finished output element besides storing it (all optional): add a residual
 // tensor of the output's shape, apply ReLU, and emit the NEXT layer's activation codes - the consumer's own
@@ -34,12 +35,16 @@ static inline bool epi_set_form(ConvEpi& ep, int32_t q_form, int32_t q_lo, int32
   return ep.q_form >= DLMCQ_FORM_EMULATE && ep.q_form <= DLMCQ_FORM_SYMMETRIC && (!shifted || (q_lo >= 0 && q_hi <= 255));
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// the quantiser of every post-ReLU tensor in the frozen plans: unsigned byte range, no zero point (EpiQuant::code4n<N, true>)
+static inline bool epi_plain(const ConvEpi& ep) { return ep.codes && !ep.q_zp && ep.q_lo == 0.0f && ep.q_hi == 255.0f; }
+
 
 // The one rounding chain of every int8 kernel: exact integer sum -> fp32, then ONE fused multiply-add with the layer's
 // (s_in * s_w[k]) and bias[k].  (Rounds 1-2a multiplied and added separately; fused is one VALU instruction fewer per element
 // in epilogues that are bound by exactly that, and one rounding closer to the real-valued result.)
 __device__ __forceinline__ float dequant1(int sum, float mult, float bias) { return __builtin_fmaf((float)sum, mult, bias); }
+// ... on a pair: v_pk_fma_f32 (one fused multiply-add per element, the same rounding)
+__device__ __forceinline__ f32x2 pk_fma(const f32x2& a, const f32x2& b, const f32x2& c) { return __builtin_elementwise_fma(a, b, c); }
 
 // torch.relu on four values (relu_nan: NaN and -0 pass) as 4 compares into 4 different SGPR pairs followed by 4 selects: the
 // compiler's rendering serialises on vcc with wait states after every compare
@@ -156,8 +161,22 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
   // The zero point rides on the multiply: t = fma(u, 1/dv, zadd) (zadd is integral, checked above), q = rint(t).  t differs
   // from d + zadd by less than M in the range that does not saturate (above), so the tie test is applied to t itself: 6 instructions per element (fma, rint, sub, compare, clamp, pack)
   // when the form has no offset to subtract first (OFZ).
-  template <bool OFZ>
+  // PLAIN (the caller has checked epi_plain on the host): unsigned byte range [0, 255], no zero point - of = zadd = 0, lo_fast = 0
+  // with or without the folded ReLU, no negative codes.  The clamp is then the saturation of v_cvt_pk_u8_f32 itself (negative -> 0,
+  // beyond 255 -> 255; a NaN has failed the tie test): 5 instructions per element (mul, rint, sub, compare, pack), same bytes.
+  template <bool OFZ, bool PLAIN = false>
   __device__ __forceinline__ uint32_t code4_fast(const f32x4& v, bool& unsure) const {
+    if constexpr (PLAIN) {
+      const float t0 = v.x * rdv, t1 = v.y * rdv, t2 = v.z * rdv, t3 = v.w * rdv;      // (= fma(v, rdv, 0) up to the sign of a zero, which nothing below sees)
+      const float r0 = __builtin_rintf(t0), r1 = __builtin_rintf(t1), r2 = __builtin_rintf(t2), r3 = __builtin_rintf(t3);
+      const float thr = tie_thr;
+      unsure = !(__builtin_fabsf(t0 - r0) < thr) | !(__builtin_fabsf(t1 - r1) < thr) | !(__builtin_fabsf(t2 - r2) < thr) |
+               !(__builtin_fabsf(t3 - r3) < thr);
+      uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(r0, 0, 0u);
+      w = __builtin_amdgcn_cvt_pk_u8_f32(r1, 1, w);
+      w = __builtin_amdgcn_cvt_pk_u8_f32(r2, 2, w);
+      return __builtin_amdgcn_cvt_pk_u8_f32(r3, 3, w) ^ xemit;
+    }
     const float u0 = OFZ ? v.x : v.x - of, u1 = OFZ ? v.y : v.y - of, u2 = OFZ ? v.z : v.z - of, u3 = OFZ ? v.w : v.w - of;
     const float t0 = __builtin_fmaf(u0, rdv, zadd), t1 = __builtin_fmaf(u1, rdv, zadd), t2 = __builtin_fmaf(u2, rdv, zadd),
                 t3 = __builtin_fmaf(u3, rdv, zadd);
@@ -185,10 +204,45 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
   }
   // N independent quads: one branch for all of them
   // `u` (optional) receives the per-quad flags, for callers that have more to redo on the exact path (a NaN's ReLU)
+  // N independent quads of a PLAIN quantiser (epi_plain), written on PAIRS (v_pk_mul_f32 / v_pk_add_f32: one instruction for two
+  // elements, the same roundings) where the instruction set has a packed form.  The tie flags stay wave masks (ballots of the
+  // compares themselves: one scalar OR each, one uniform branch for all quads); a quad with a flagged lane anywhere in the wave is
+  // redone by exact4 in every lane - which re-tests each element itself and returns the fast byte or the exact one, the same byte
+  // either way (the fast path's proof holds per element).
   template <int N>
+  __device__ __forceinline__ void code4n_plain(const f32x4 (&v)[N], uint32_t (&w)[N]) const {
+    uint64_t bal[N], any = 0;
+    const f32x2 rdv2 = f32x2{rdv, rdv};
+    const float thr = tie_thr;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const f32x2 ta = f32x2{v[i].x, v[i].y} * rdv2, tb = f32x2{v[i].z, v[i].w} * rdv2;    // (= fma(v, rdv, 0) up to the sign of a zero, which nothing below sees)
+      const f32x2 ra = f32x2{__builtin_rintf(ta.x), __builtin_rintf(ta.y)}, rb = f32x2{__builtin_rintf(tb.x), __builtin_rintf(tb.y)};
+      const f32x2 da = ta - ra, db = tb - rb;
+      bal[i] = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(da.x) < thr)) | __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(da.y) < thr)) |
+               __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(db.x) < thr)) | __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(db.y) < thr));
+      any |= bal[i];
+      uint32_t c = __builtin_amdgcn_cvt_pk_u8_f32(ra.x, 0, 0u);       // saturates: negative -> 0 (the folded ReLU, the lower bound), beyond 255 -> 255
+      c = __builtin_amdgcn_cvt_pk_u8_f32(ra.y, 1, c);
+      c = __builtin_amdgcn_cvt_pk_u8_f32(rb.x, 2, c);
+      w[i] = __builtin_amdgcn_cvt_pk_u8_f32(rb.y, 3, c) ^ xemit;
+    }
+    if (__builtin_expect(any != 0, false)) {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (bal[i]) w[i] = exact4(v[i], w[i]);
+    }
+  }
+  template <int N, bool PLAIN = false>
   __device__ __forceinline__ bool code4n(const f32x4 (&v)[N], uint32_t (&w)[N], bool (&u)[N]) const {
     bool any = false;
-    if (of == 0.0f) {
+    if constexpr (PLAIN) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        w[i] = code4_fast<true, true>(v[i], u[i]);
+        any |= u[i];
+      }
+    } else if (of == 0.0f) {
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         w[i] = code4_fast<true>(v[i], u[i]);

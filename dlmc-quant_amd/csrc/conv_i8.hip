@@ -932,6 +932,14 @@ extern "C" int dlmcq_x_conv2d_i8_tuned(const void* x, const int8_t* w, float* ou
                                stride, x_is_unsigned ? 128 : 0, e2, reinterpret_cast<hipStream_t>(stream), -pp_wps - 100,
                                const_cast<float*>(residual));
   }
+  if (pp_wps <= -40 && pp_wps > -100) {   // ... of the pointwise kernel (LAB = -pp_wps - 40; `bias` doubles as the weight offsets, `residual` as the stamp buffer)
+    ConvEpi e2 = ep;
+    e2.residual = nullptr;
+    e2.w_off = bias;
+    if (!conv_pw_applies(N, H, W, C, K, R, S, stride, pad, dilation, e2, out, false)) return DLMCQ_EINVAL;
+    return conv_pw_launch(reinterpret_cast<const int8_t*>(x), w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K,
+                          x_is_unsigned ? 128 : 0, e2, reinterpret_cast<hipStream_t>(stream), -pp_wps - 40, const_cast<float*>(residual));
+  }
   if (pp_wps <= -20 && pp_wps > -100) {   // ... of the swapped asymmetric kernels (LAB = -pp_wps - 20, 0 = as built; `bias` doubles as the weight offsets)
     const int64_t P = (H + 2 * pad - dilation * (R - 1) - 1) / stride + 1, Q = (W + 2 * pad - dilation * (S - 1) - 1) / stride + 1;
     if (C % CV_BK || K % bn || (bn != 128 && bn != 192) || P < 1 || Q < 1 || N * P * Q >= (1ll << 31) || !ep.codes || out) return DLMCQ_EINVAL;

@@ -86,6 +86,9 @@ __device__ __forceinline__ void bstore16(const f32x4& v, int voff, const v4i& rs
 __device__ __forceinline__ void bstore16i(const i32x4& v, int voff, const v4i& rsrc) {
   asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
+__device__ __forceinline__ void bstore16i_nt(const i32x4& v, int voff, const v4i& rsrc) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
 constexpr int BUF_BIG = 0x7fff0000;   // a byte offset beyond every buffer these kernels accept (< 2^31 - 64 KiB)
 
 // conv3x3_i8.hip: the halo-tile kernel for 3x3 / stride 1 or 2 / pad 1 layers that emit only their consumer's codes
@@ -100,7 +103,7 @@ bool conv_pw_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int6
                      int32_t dilation, const ConvEpi& ep, const float* out, bool dual);
 int conv_pw_launch(const int8_t* x, const int8_t* w, const float* bias, const int32_t* wsum, const float* in_scale,
                    const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int shift,
-                   const ConvEpi& ep, hipStream_t st);
+                   const ConvEpi& ep, hipStream_t st, int lab = 0, void* lab_trace = nullptr);
 
 // conv_stem_pool7_i8.hip: the ResNet first layer (7x7 / 2 + ReLU + 3x3 / 2 max-pool + quantiser) with the pooling in registers
 bool stem_pool7_applies(int64_t Hp, int64_t Wp, int64_t K, int64_t R, int64_t S, int32_t stride, const float* out, const void* codes);

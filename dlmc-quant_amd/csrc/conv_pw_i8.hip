@@ -29,12 +29,15 @@ struct PwArgs {
   const float* zp_in;      // null: 0
   int M, K, shift, nslice; // nslice = K / BN column slices; workgroup b: slice (b >> 3) % nslice, group ((b >> 3) / nslice) * 8 + (b & 7)
   int nblk;                // 32-pixel blocks
+  unsigned long long* trace;   // lab builds: clock stamps of one wave (tools/pw_lab.py --trace); null otherwise
 };
 
-// registers decide the waves per SIMD: A fragments C / 8 + accumulators BN / 2 + ~45 for the epilogue
-constexpr int PW_WPS(int c, int bn) { return 3; }
+// waves per SIMD the kernel is compiled for (registers: fragments C / 8 + accumulators of one pass + ~70 for the epilogue)
+constexpr int PW_WPS(int c, int bn) { return c >= 512 ? 3 : 4; }
 
-template <int C, int BN, int NTP, bool ASYM, int NW>
+// LAB (lab library only, what-bounds-the-block experiments: results are garbage): 1 = clock stamps of one wave, 2 = no activation
+// loads, 4 = no MFMAs, 6 = epilogue without its arithmetic, 7 = no epilogue and no stores, 8 = no stores, 9 = non-temporal stores
+template <int C, int BN, int NTP, bool ASYM, int NW, int LAB = 0>
 __global__ __launch_bounds__(NW * 64, PW_WPS(C, BN)) void conv_pw_i8_kernel(PwArgs a, ConvEpi ep) {
   constexpr int S = C / 64;             // 64-byte K steps
   constexpr int NA = C / 32;            // A fragments (16 bytes per lane each)
@@ -48,6 +51,11 @@ __global__ __launch_bounds__(NW * 64, PW_WPS(C, BN)) void conv_pw_i8_kernel(PwAr
   extern __shared__ __attribute__((aligned(1024))) int8_t pw_lds[];
   int8_t* const wl = pw_lds;                    // [S][BN rows][64 B], LDS slot p of row r = logical segment p ^ ((r >> 2) & 3)
   int8_t* const par = pw_lds + WB;              // s_in s_w | (shift - zp) SUM qw | bias | s_in o_w
+  constexpr int SROW = BN + 16;                 // a staged row of codes (+ 16: conflict-free 16-byte accesses)
+  constexpr int LPR = BN / 16, RPI = 64 / LPR;  // lanes per staged row, whole rows per wave-instruction (192 channels: 5, four lanes idle)
+  constexpr int NST = (32 + RPI - 1) / RPI;     // store instructions per block
+  int8_t* const stg = pw_lds + WB + 4 * BN * 4 + (threadIdx.x >> 6) * (32 * SROW);   // this wave's 32 rows
+  const int srow = (int)((threadIdx.x & 63) / LPR), sseg = (int)(threadIdx.x & 63) - srow * LPR;   // this lane's place in a row-major read of the stage
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
   const uint32_t b = blockIdx.x;
@@ -56,12 +64,32 @@ __global__ __launch_bounds__(NW * 64, PW_WPS(C, BN)) void conv_pw_i8_kernel(PwAr
   const int ngroups = (int)(gridDim.x / (uint32_t)a.nslice);
   const int n0 = slice * BN;
 
+  // lab builds: clock stamps of wave 0 of the middle workgroup: [0] real-time clock (100 MHz) at entry, [1] at exit, [2] stamps written,
+  // [3...] shader clocks: entry, loop entered, then per block: loop top, fragments landed, (K loop, epilogue) per pass, stores issued
+  unsigned long long* tr = nullptr;
+  if (LAB == 1 && a.trace && blockIdx.x == gridDim.x / 2 && tid == 0) tr = a.trace;
+  int nstamp = 3;
+  auto stamp = [&]() {
+    if (LAB == 1 && tr && nstamp < 256) tr[nstamp++] = __builtin_readcyclecounter();
+  };
+  if (LAB == 1 && tr) tr[0] = __builtin_amdgcn_s_memrealtime();
+  stamp();
+  unsigned long long* wgt = nullptr;     // ... and per workgroup behind those 256 slots: real-time clock at entry / exit, HW_ID, XCC_ID
+  if (LAB == 1 && a.trace && tid == 0) {
+    wgt = a.trace + 256 + 4 * (size_t)blockIdx.x;
+    wgt[0] = __builtin_amdgcn_s_memrealtime();
+    wgt[2] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    wgt[3] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+  }
   // ---- once per workgroup: constants and weights by LDS-DMA ----
   {
     const void* arrs[4] = {a.s_w, a.wsum, a.bias, ASYM ? ep.w_off : nullptr};
 #pragma unroll
     for (int r = 0; r < NPAR; ++r) {
-      if (!arrs[r]) continue;
+      if (!arrs[r]) {                                  // (no bias: zeros, so that the epilogue reads a table either way)
+        for (int c = tid; c < BN; c += NW * 64) reinterpret_cast<float*>(par)[r * BN + c] = 0.0f;
+        continue;
+      }
       for (int c = wave; c < BN / 64; c += NW)
         __builtin_amdgcn_global_load_lds((gptr_t)(static_cast<const int32_t*>(arrs[r]) + n0 + c * 64 + lane), (lptr_t)(par + (r * BN + c * 64) * 4), 4, 0, 0);
     }
@@ -87,6 +115,11 @@ __global__ __launch_bounds__(NW * 64, PW_WPS(C, BN)) void conv_pw_i8_kernel(PwAr
   auto request = [&](int blk) {       // this lane's fragments of block `blk`: bytes 32 f + 16 hsel .. + 15 of pixel 32 blk + l31
     const int row = blk * 32 + l31;
     const int vo = (blk < a.nblk && row < a.M) ? row * C + hsel * 16 : BUF_BIG;
+    if constexpr (LAB == 2) {
+#pragma unroll
+      for (int f = 0; f < NA; ++f) areg[f] = i32x4{vo, 1, 2, 3};
+      return;
+    }
     static_for<NA>([&](auto f) { bload16i<decltype(f)::value * 32>(areg[decltype(f)::value], vo, r_x); });
   };
   const int stride = ngroups * NW;
@@ -103,32 +136,44 @@ __global__ __launch_bounds__(NW * 64, PW_WPS(C, BN)) void conv_pw_i8_kernel(PwAr
   }
   __syncthreads();
 
-  bool first = true;
+  stamp();
   for (; blk < a.nblk; blk += stride) {
-    // this block's fragments have landed; the previous block's last NTP - JP stores may still be in flight (first block: nothing younger)
-    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTP - JP) : "memory");
-    first = false;
+    // this block's fragments have landed (the first block's: the prologue waited for everything); the previous block's NST stores
+    // may still be in flight
+    stamp();
+    if constexpr (LAB == 2 || LAB == 7 || LAB == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    stamp();
 #pragma unroll
-    for (int f = 0; f < NA; ++f) asm volatile("" : "+v"(areg[f]));     // the asm-loaded fragments are valid from here on
-    const int row = blk * 32 + l31;
-    const int so = row < a.M ? row * a.K + n0 + hsel * 16 : BUF_BIG;
-    float s0f = 0.0f;
+    for (int f = 0; f < NA; ++f) {
+      asm volatile("" : "+v"(areg[f]));     // the asm-loaded fragments are valid from here on
+      areg[f] = i32x4{(int)(areg[f].x ^ xorw), (int)(areg[f].y ^ xorw), (int)(areg[f].z ^ xorw), (int)(areg[f].w ^ xorw)};   // uint8 -> int8, once for all passes
+    }
+    f32x2 s0f2 = f32x2{0.0f, 0.0f};
     // NP passes over NTP accumulator blocks each (the fragments stay in registers; what a pass holds besides them is NTP x 16
     // accumulators and the epilogue's ~70 registers)
     static_for<NP>([&](auto p_c) {
       constexpr int p = decltype(p_c)::value;
+      // the accumulators start from (shift - zp) * SUM qw of their channels (register i of block j: channel 32 j + 16 hsel + i):
+      // four LDS reads instead of sixteen additions per block
       i32x16 acc[NTP];
 #pragma unroll
-      for (int j = 0; j < NTP; ++j)
+      for (int j = 0; j < NTP; ++j) {
+        const i32x4* cop = reinterpret_cast<const i32x4*>(par + (BN + (p * NTP + j) * 32 + hsel * 16) * 4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0;
+        for (int q = 0; q < 4; ++q) {
+          const i32x4 c4 = cop[q];
+          acc[j][4 * q] = c4.x;
+          acc[j][4 * q + 1] = c4.y;
+          acc[j][4 * q + 2] = c4.z;
+          acc[j][4 * q + 3] = c4.w;
+        }
+      }
       int s0 = 0;
       static_for<NA>([&](auto f_c) {
         constexpr int f = decltype(f_c)::value;
         constexpr int s = f >> 1, ks = f & 1;
-        const i32x4 t = areg[f];
-        const i32x4 af = i32x4{(int)(t.x ^ xorw), (int)(t.y ^ xorw), (int)(t.z ^ xorw), (int)(t.w ^ xorw)};
+        const i32x4 af = areg[f];
         if constexpr (ASYM && p == 0) {
           s0 = __builtin_amdgcn_sdot4(af.x, 0x01010101, s0, false);
           s0 = __builtin_amdgcn_sdot4(af.y, 0x01010101, s0, false);
@@ -140,14 +185,19 @@ __global__ __launch_bounds__(NW * 64, PW_WPS(C, BN)) void conv_pw_i8_kernel(PwAr
         for (int j = 0; j < NTP; ++j) {
           const int brow = (p * NTP + j) * 32 + l31;
           const i32x4 bf = *reinterpret_cast<const i32x4*>(wl + s * (BN * 64) + brow * 64 + ((sg ^ ((brow >> 2) & 3)) << 4));
-          acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf, af, acc[j], 0, 0, 0);
+          if constexpr (LAB == 4) asm volatile("" ::"v"(af), "v"(bf));
+          else acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf, af, acc[j], 0, 0, 0);
         }
       });
+      if constexpr (LAB == 1) {
+        asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[NTP - 1][15]));
+        stamp();
+      }
       // ---- the swapped epilogue (conv_i8.hip): register i of block j = channel n0 + 32 j + 16 hsel + i of pixel `row` ----
       if constexpr (ASYM && p == 0) {
         s0 += __shfl_xor(s0, 32, 64);
         s0 += (a.shift - zpi) * C;
-        s0f = (float)s0;
+        s0f2 = f32x2{(float)s0, (float)s0};
       }
 #pragma unroll
       for (int jj = 0; jj < NTP; ++jj) {
@@ -157,25 +207,68 @@ __global__ __launch_bounds__(NW * 64, PW_WPS(C, BN)) void conv_pw_i8_kernel(PwAr
         if (p == NP - 1 && jj == JP) request(blk + stride);
         const int j = p * NTP + jj;
         const int cb = j * 32 + hsel * 16;
+        if constexpr (LAB == 6 || LAB == 7) {
+          uint32_t wl4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            wl4[q] = (uint32_t)(acc[jj][4 * q] & 0xff) | ((uint32_t)(acc[jj][4 * q + 1] & 0xff) << 8) | ((uint32_t)(acc[jj][4 * q + 2] & 0xff) << 16) |
+                     ((uint32_t)acc[jj][4 * q + 3] << 24);
+          if constexpr (LAB == 6) *reinterpret_cast<i32x4*>(stg + l31 * SROW + cb) = i32x4{(int)wl4[0], (int)wl4[1], (int)wl4[2], (int)wl4[3]};
+          else asm volatile("" ::"v"(wl4[0]), "v"(wl4[1]), "v"(wl4[2]), "v"(wl4[3]));
+          continue;
+        }
+        // on pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same roundings as conv_i8.hip's scalar chain, half the instructions)
         f32x4 y[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 mu = *reinterpret_cast<const f32x4*>(par + (cb + 4 * q) * 4);
-          const i32x4 co = *reinterpret_cast<const i32x4*>(par + (BN + cb + 4 * q) * 4);
-          const f32x4 bs = a.bias ? *reinterpret_cast<const f32x4*>(par + (2 * BN + cb + 4 * q) * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-          y[q] = f32x4{dequant1(acc[jj][4 * q] + co.x, mu.x, bs.x), dequant1(acc[jj][4 * q + 1] + co.y, mu.y, bs.y),
-                       dequant1(acc[jj][4 * q + 2] + co.z, mu.z, bs.z), dequant1(acc[jj][4 * q + 3] + co.w, mu.w, bs.w)};
+          const f32x4 bs = *reinterpret_cast<const f32x4*>(par + (2 * BN + cb + 4 * q) * 4);
+          f32x2 ya = pk_fma(f32x2{(float)acc[jj][4 * q], (float)acc[jj][4 * q + 1]}, f32x2{mu.x, mu.y}, f32x2{bs.x, bs.y});
+          f32x2 yb = pk_fma(f32x2{(float)acc[jj][4 * q + 2], (float)acc[jj][4 * q + 3]}, f32x2{mu.z, mu.w}, f32x2{bs.z, bs.w});
           if constexpr (ASYM) {
             const f32x4 wo = *reinterpret_cast<const f32x4*>(par + (3 * BN + cb + 4 * q) * 4);
-            y[q] = f32x4{y[q].x + s0f * wo.x, y[q].y + s0f * wo.y, y[q].z + s0f * wo.z, y[q].w + s0f * wo.w};
+            ya = ya + s0f2 * f32x2{wo.x, wo.y};
+            yb = yb + s0f2 * f32x2{wo.z, wo.w};
           }
+          y[q] = f32x4{ya.x, ya.y, yb.x, yb.y};
         }
         uint32_t wq[4];
-        bool uq[4];
-        eq.code4n(y, wq, uq);
-        bstore16i(i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]}, so == BUF_BIG ? BUF_BIG : so + j * 32, r_c);
+        eq.code4n_plain(y, wq);
+        // the block's 16 bytes of this pixel wait in the wave's LDS stage: the stores below leave as whole rows (a store straight
+        // from here writes 32 contiguous bytes per pixel - 32 partial lines per instruction - and the layer spends half its
+        // time in them: tools/pw_lab.py, 192 -> 192 at 28^2 95 us with, 43 without its stores and arithmetic, 91 with the stores alone)
+        *reinterpret_cast<i32x4*>(stg + l31 * SROW + cb) = i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
       }
+      stamp();
     });
+    if constexpr (LAB != 7) {
+      // row-major out of the stage: LPR lanes x 16 bytes per row (LDS operations of one wave execute in order: no barrier)
+      // (one per-lane byte offset for the block, the per-instruction steps are scalars: nothing per instruction lives in a register)
+      const int r0 = blk * 32 + srow;
+      const int vbase = r0 * a.K + n0 + sseg * 16;
+      const int8_t* const sbase = stg + srow * SROW + sseg * 16;
+#pragma unroll
+      for (int it = 0; it < NST; ++it) {
+        const bool ok = srow < RPI && it * RPI + srow < 32 && r0 + it * RPI < a.M;
+        // (the last instruction may reach past row 31 - into the next wave's stage or past the allocation: its lanes read row 31 instead and store nothing)
+        const bool whole = (it + 1) * RPI <= 32;
+        const i32x4 c16 = *reinterpret_cast<const i32x4*>(whole || it * RPI + srow < 32 ? sbase + it * RPI * SROW : stg + 31 * SROW + sseg * 16);
+        if constexpr (LAB == 8) asm volatile("" ::"v"(c16));
+        else if constexpr (LAB == 9) bstore16i_nt(c16, ok ? vbase + it * RPI * a.K : BUF_BIG, r_c);
+        else bstore16i(c16, ok ? vbase + it * RPI * a.K : BUF_BIG, r_c);
+      }
+    }
+    stamp();
+  }
+  if (LAB == 1 && tr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();
+    tr[1] = __builtin_amdgcn_s_memrealtime();
+    tr[2] = (unsigned long long)nstamp;
+  }
+  if (LAB == 1 && wgt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wgt[1] = __builtin_amdgcn_s_memrealtime();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the requests past the end: nothing may be in flight into registers at s_endpgm)
 }
@@ -184,6 +277,7 @@ __global__ __launch_bounds__(NW * 64, PW_WPS(C, BN)) void conv_pw_i8_kernel(PwAr
 bool conv_pw_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
                      int32_t dilation, const ConvEpi& ep, const float* out, bool dual) {
   if (R != 1 || S != 1 || stride != 1 || pad != 0 || dilation != 1 || dual || out || ep.residual || !ep.codes) return false;
+  if (!epi_plain(ep)) return false;                             // (other quantisers: the tiled kernel)
   if (!(C == 64 || C == 128 || C == 192 || C == 512)) return false;
   if (!(K == 192 || K % 128 == 0) || K > 1024) return false;
   if (!aligned16(ep.codes)) return false;
@@ -193,13 +287,15 @@ bool conv_pw_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int6
   return true;
 }
 
-template <int C, int BN, bool ASYM>
+template <int C, int BN, bool ASYM, int LAB = 0>
 static int pw_go(const PwArgs& a0, const ConvEpi& ep, hipStream_t st) {
   constexpr int WPS = PW_WPS(C, BN);
-  constexpr int LDS = C * BN + 4 * BN * 4;
+  constexpr int LDS1 = C * BN + 4 * BN * 4, STG = 4 * 32 * (BN + 16);   // weights + constants; one 4-wave workgroup's code stages
   // workgroups of 4 waves where WPS of them fit a CU's LDS, else ONE workgroup of 4 WPS waves per CU (one copy of the weights)
-  constexpr bool BIGWG = LDS * WPS > 150 * 1024;
+  constexpr bool BIGWG = (LDS1 + STG) * WPS > 158 * 1024;
   constexpr int NW = BIGWG ? 4 * WPS : 4;
+  constexpr int LDS = LDS1 + (NW / 4) * STG;
+  static_assert(LDS <= 160 * 1024, "LDS");
   PwArgs a = a0;
   a.nslice = a.K / BN;
   static int cus = 0;      // (one device per process: dlmc/_native.py)
@@ -214,8 +310,8 @@ static int pw_go(const PwArgs& a0, const ConvEpi& ep, hipStream_t st) {
   if (ngroups < 8) ngroups = 8;
   const int maxg = ((a.nblk + NW - 1) / NW + 7) & ~7;
   if (ngroups > maxg) ngroups = maxg;
-  constexpr int NTP = BN == 192 ? 3 : (C >= 512 ? 1 : BN / 32);
-  auto kern = conv_pw_i8_kernel<C, BN, NTP, ASYM, NW>;
+  constexpr int NTP = BN == 192 ? 3 : (C >= 512 ? 1 : 2);
+  auto kern = conv_pw_i8_kernel<C, BN, NTP, ASYM, NW, LAB>;
   static bool attr_set = false;
   if (!attr_set) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -228,13 +324,26 @@ static int pw_go(const PwArgs& a0, const ConvEpi& ep, hipStream_t st) {
 
 int conv_pw_launch(const int8_t* x, const int8_t* w, const float* bias, const int32_t* wsum, const float* in_scale,
                    const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int shift,
-                   const ConvEpi& ep, hipStream_t st) {
+                   const ConvEpi& ep, hipStream_t st, int lab, void* lab_trace) {
   PwArgs a{};
+  a.trace = static_cast<unsigned long long*>(lab_trace);
   a.x = x; a.w = w; a.s_w = w_scale; a.wsum = wsum; a.bias = bias; a.s_in = in_scale; a.zp_in = in_zero_point;
   a.M = (int)(N * H * W); a.K = (int)K; a.shift = shift;
   a.nblk = (a.M + 31) / 32;
   const bool asym = ep.w_off != nullptr;
   const int bn = K == 192 ? 192 : 128;
+#ifdef DLMCQ_LAB
+#define DLMCQ_PWL(CC, BB, L) \
+  if (C == CC && bn == BB && lab == L && asym) return pw_go<CC, BB, true, L>(a, ep, st)
+#define DLMCQ_PWLS(CC, BB) DLMCQ_PWL(CC, BB, 1); DLMCQ_PWL(CC, BB, 2); DLMCQ_PWL(CC, BB, 4); DLMCQ_PWL(CC, BB, 6); DLMCQ_PWL(CC, BB, 7); DLMCQ_PWL(CC, BB, 8); DLMCQ_PWL(CC, BB, 9)
+  DLMCQ_PWLS(128, 128);
+  DLMCQ_PWLS(192, 192);
+  DLMCQ_PWLS(192, 128);
+  DLMCQ_PWLS(512, 128);
+#undef DLMCQ_PWLS
+#undef DLMCQ_PWL
+#endif
+  if (lab) return DLMCQ_EINVAL;
 #define DLMCQ_PW(CC, BB)                                         \
   if (C == CC && bn == BB) return asym ? pw_go<CC, BB, true>(a, ep, st) : pw_go<CC, BB, false>(a, ep, st)
   DLMCQ_PW(64, 128);

@@ -22,44 +22,63 @@ SRC = os.path.join(ROOT, "dlmc-quant_amd", "csrc", "conv_pw_i8.hip")
 
 
 def in_flight_check(name, body, nfrag):
-    """The block loop's text = every basic block annotated `in Loop: Header=<the depth-1 loop behind the prologue's barriers>` (the
-    latch may be laid out in front of the header).  From each fragment load the listing is walked forward to the end of that text,
-    then on from its start, up to the counted wait; any touch of the load's registers on the way is a problem."""
+    """Control-flow walk: from every fragment load inside the block loop, every instruction reachable before a `s_waitcnt vmcnt`
+    (fall-through, both ways of a conditional branch, the target of an unconditional one; rarely executed blocks are laid out far
+    from the loop, so the listing's order says nothing) must leave the load's registers alone."""
+    label_at = {}
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            label_at[m.group(1)] = i
     bars = [i for i, l in enumerate(body) if "s_barrier" in l]
     heads = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l and "=>" in l and bars and i > bars[-1]]
     if not heads:
         print(f"{name}: block loop header not found")
         return 1
-    head = heads[0]
-    tag = "Header=" + body[head].split(":")[0].strip().lstrip(".L")
-    labels = [i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
-    member = [i for i in labels if tag in body[i]] + [head]
-    lo = min(member)
-    last = max(member)
-    hi = next((i for i in labels if i > last), len(body)) - 1
-    loads = [(i, re.search(r"buffer_load_dwordx4 v\[(\d+):(\d+)\]", body[i])) for i in range(lo, hi + 1) if "buffer_load_dwordx4" in body[i]]
+    tag = "Header=" + body[heads[0]].split(":")[0].strip().lstrip(".L")
+
+    def in_loop(i):          # the basic block of line i belongs to the block loop (its label line says so; the header itself does)
+        j = i
+        while j >= 0 and not re.match(r"^\.LBB\d+_\d+:", body[j]) and "; %bb." not in body[j]:
+            j -= 1
+        return j >= 0 and (tag in body[j] or j == heads[0])
+    loads = [(i, re.search(r"buffer_load_dwordx4 v\[(\d+):(\d+)\]", body[i])) for i in range(len(body))
+             if "buffer_load_dwordx4" in body[i] and i > bars[-1] and in_loop(i)]
     bad = 0
     if len(loads) != nfrag:          # a vacuous pass is a failure
         print(f"{name}: {len(loads)} fragment loads inside the block loop, expected {nfrag}")
         bad += 1
     for i, m in loads:
         mine = set(range(int(m.group(1)), int(m.group(2)) + 1))
-        j, steps = i + 1, 0
-        while steps < 2 * (hi - lo + 1):
-            if j > hi:
-                j = lo
-            line = body[j]
-            if "s_waitcnt" in line and "vmcnt(" in line:
-                break
-            if "buffer_load_dwordx4" not in line:
-                hit = regs(line) & mine
-                if hit:
-                    print(f"{name}: line {j}: `{line.strip()}` touches registers {sorted(hit)} of the load at line {i} still in flight")
+        seen, todo, waited = set(), [i + 1], 0
+        while todo:
+            j = todo.pop()
+            while j < len(body) and j not in seen:
+                seen.add(j)
+                line = body[j].split(";")[0].strip()
+                if not line or line.endswith(":"):
+                    j += 1
+                    continue
+                if line.startswith("s_waitcnt") and "vmcnt(" in line:
+                    waited += 1
+                    break
+                if "buffer_load_dwordx4" not in line:
+                    hit = regs(line) & mine
+                    if hit:
+                        print(f"{name}: line {j}: `{line}` touches registers {sorted(hit)} of the load at line {i} still in flight")
+                        bad += 1
+                if line.startswith("s_endpgm"):
+                    print(f"{name}: the kernel can end with the load at line {i} in flight (no vmcnt wait on the way)")
                     bad += 1
-            j += 1
-            steps += 1
-        else:
-            print(f"{name}: no vmcnt wait found behind the load at line {i}")
+                    break
+                mb = re.match(r"(s_branch|s_cbranch_\w+)\s+(\.LBB\d+_\d+)", line)
+                if mb:
+                    todo.append(label_at[mb.group(2)])
+                    if mb.group(1) == "s_branch":
+                        break
+                j += 1
+        if not waited:
+            print(f"{name}: no vmcnt wait reachable from the load at line {i}")
             bad += 1
     return bad
 
@@ -67,7 +86,7 @@ def in_flight_check(name, body, nfrag):
 def main():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "pw.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-o", out, SRC], stderr=subprocess.DEVNULL)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-fno-slp-vectorize", "-o", out, SRC], stderr=subprocess.DEVNULL)   # (csrc/Makefile: EXTRA_conv_pw_i8)
         text = open(out).read().splitlines()
     kernels, cur = {}, None
     for line in text:
