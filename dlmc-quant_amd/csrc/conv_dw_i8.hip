@@ -25,6 +25,7 @@ __device__ __forceinline__ f32x4 bytes_s(uint32_t a) {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int DW_BIG = 0x7fff0000;      // a byte offset beyond every tensor the buffer-addressed tap loads accept
 
 // 3 x 3, 16 channels per thread (C % 16 == 0): every tap is ONE 16-byte load per lane, all 9 taps requested before the first
 // is used; a tap outside the image reads a clamped address and is replaced by the zero point.  The first version converted
@@ -160,6 +161,12 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
 // a dword holds columns q-1 .. q+2 of one channel - so one transposition serves both pixels: pixel A multiplies it with
 // [w0 w1 w2 0], pixel B with [0 w0 w1 w2] (both packed once per workgroup).  Per output element: 3 instead of 5 byte permutes, the
 // channel's LDS records read once per pair.  Same integer sums, same fp32 chain: bit-identical to conv_dw3_i8_kernel.
+// FAST (round 4; the kernel is bound by its ~31 vector instructions per element, one per 4 clocks and SIMD): 1 / 2 = codes-only layer
+// with the plain unsigned-byte quantiser (epi_plain), asymmetric / symmetric weights known at compile time - the fp32 chain on PAIRS
+// of channels (v_pk_mul_f32 / v_pk_add_f32 on constants stored as pairs: the same roundings, half the instructions), the
+// quantiser of both pixels behind one branch with its clamp left to v_cvt_pk_u8_f32 (EpiQuant::code4n_plain), no flag tests per
+// element.  0 = everything else, as before.  Bit-identical where both apply.
+template <int FAST>
 __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4* __restrict__ x, const int8_t* __restrict__ w,
                                                                    float* __restrict__ out, const float* __restrict__ bias,
                                                                    const float* __restrict__ s_in, const float* __restrict__ zp_in,
@@ -169,11 +176,12 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4*
   const int C = g.C4 * 4, C16 = g.C4 >> 2;
   u32x4* tabA = reinterpret_cast<u32x4*>(dw_lds);            // [16][C16]: {row 0, row 1, row 2 of pixel A's weights, dzw}
   u32x4* tabB = tabA + C;                                    // [16][C16]: {rows of pixel B's weights (one byte up), -}
-  f32x4* tabp = reinterpret_cast<f32x4*>(tabB + C);          // [16][C16]: {m, mo, b, -}
+  f32x4* tabp = reinterpret_cast<f32x4*>(tabB + C);          // [16][C16]: {m, mo, b, -};  FAST: [8][C16] {m, m', mo, mo'} of a channel PAIR,
+  f32x2* tabb = reinterpret_cast<f32x2*>(tabp + C / 2);      //                             then [8][C16] {b, b'} (zeros without a bias)
   const float sin = s_in[0], zp = zp_in ? zp_in[0] : 0.0f;
   const int zpi = (int)zp;
   const int dz = (x_signed ? 0 : 128) - zpi;
-  const bool asym = o_w != nullptr;
+  const bool asym = FAST ? FAST == 1 : o_w != nullptr;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     uint32_t ra[3];
     int sum = 0;
@@ -190,9 +198,19 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4*
     const int slot = (c & 15) * C16 + (c >> 4);
     tabA[slot] = u32x4{ra[0], ra[1], ra[2], (uint32_t)(dz * sum)};
     tabB[slot] = u32x4{ra[0] << 8, ra[1] << 8, ra[2] << 8, 0u};
-    tabp[slot] = f32x4{sin * s_w[c], asym ? sin * o_w[c] : 0.0f, bias ? bias[c] : 0.0f, 0.0f};
+    if constexpr (FAST) {
+      const int ps = ((c & 15) >> 1) * C16 + (c >> 4), e = c & 1;
+      reinterpret_cast<float*>(tabp + ps)[e] = sin * s_w[c];
+      reinterpret_cast<float*>(tabp + ps)[2 + e] = asym ? sin * o_w[c] : 0.0f;
+      reinterpret_cast<float*>(tabb + ps)[e] = bias ? bias[c] : 0.0f;
+    } else {
+      tabp[slot] = f32x4{sin * s_w[c], asym ? sin * o_w[c] : 0.0f, bias ? bias[c] : 0.0f, 0.0f};
+    }
   }
   __syncthreads();
+  const int64_t xbytes = (int64_t)g.N * g.H * g.W * C;
+  const bool bufpath = zpi == 0 && xbytes < (int64_t)DW_BIG;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(x), 0, bufpath ? (int)xbytes : 0, 0x00020000);
   const int QP = (g.Q + 1) >> 1;                             // pixel pairs per output row
   const int64_t total = (int64_t)g.N * g.P * QP * C16;
   const uint32_t zpw = (uint32_t)(zpi & 0xff) * 0x01010101u;
@@ -212,7 +230,24 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4*
     u32x4 a[3][4];
     const u32x4* img = x + (int64_t)n * g.H * g.W * C16 + c16;
     const bool inside = h0 >= 0 && w0 >= 0 && h0 + 2 < g.H && w0 + 3 < g.W;
-    if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
+    if (bufpath) {
+      // zero point 0 (every post-ReLU tensor): a tap outside the image is a buffer load beyond the tensor's end, which returns the zero
+      // bytes the tap stands for - one compare per row and column, one select per tap, for every wave alike.  (The clamped reads of
+      // the general path below cost a wave at the border ~250 vector instructions, and a third of the waves of a 28 x 28 image are.)
+      const int base0 = (int)(((uint32_t)n * (uint32_t)g.H + (uint32_t)h0) * (uint32_t)g.W + (uint32_t)w0) * C + c16 * 16;   // (wraps for h0 = -1 / w0 = -1: used only where valid)
+      bool cok[4];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) cok[s_] = (uint32_t)(w0 + s_) < (uint32_t)g.W;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const bool rok = (uint32_t)(h0 + r) < (uint32_t)g.H;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          const int vo = (rok && cok[s_]) ? base0 + (r * g.W + s_) * C : DW_BIG;
+          a[r][s_] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0) ^ xw;
+        }
+      }
+    } else if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
       const u32x4* p0 = img + ((int64_t)h0 * g.W + w0) * C16;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
@@ -246,6 +281,50 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4*
         Rw[r][3] = __builtin_amdgcn_perm(h23, h01, 0x07060302u);
       }
       f32x4 vA, vB;
+      if constexpr (FAST != 0) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {                               // channels c + 4d + 2jp, + 1
+          int sA[2], sB[2], zA[2] = {0, 0}, zB[2] = {0, 0};
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int j = 2 * jp + e;
+            const u32x4 ta = tabA[(d * 4 + j) * C16 + c16];
+            const u32x4 tb = tabB[(d * 4 + j) * C16 + c16];
+            sA[e] = __builtin_amdgcn_sdot4((int)Rw[0][j], (int)ta.x, (int)ta.w, false);
+            sA[e] = __builtin_amdgcn_sdot4((int)Rw[1][j], (int)ta.y, sA[e], false);
+            sA[e] = __builtin_amdgcn_sdot4((int)Rw[2][j], (int)ta.z, sA[e], false);
+            sB[e] = __builtin_amdgcn_sdot4((int)Rw[0][j], (int)tb.x, (int)ta.w, false);
+            sB[e] = __builtin_amdgcn_sdot4((int)Rw[1][j], (int)tb.y, sB[e], false);
+            sB[e] = __builtin_amdgcn_sdot4((int)Rw[2][j], (int)tb.z, sB[e], false);
+            if constexpr (FAST == 1) {
+              zA[e] = __builtin_amdgcn_sdot4((int)Rw[0][j], 0x00010101, 9 * dz, false);
+              zA[e] = __builtin_amdgcn_sdot4((int)Rw[1][j], 0x00010101, zA[e], false);
+              zA[e] = __builtin_amdgcn_sdot4((int)Rw[2][j], 0x00010101, zA[e], false);
+              zB[e] = __builtin_amdgcn_sdot4((int)Rw[0][j], 0x01010100, 9 * dz, false);
+              zB[e] = __builtin_amdgcn_sdot4((int)Rw[1][j], 0x01010100, zB[e], false);
+              zB[e] = __builtin_amdgcn_sdot4((int)Rw[2][j], 0x01010100, zB[e], false);
+            }
+          }
+          const f32x4 mm = tabp[(d * 2 + jp) * C16 + c16];             // {m, m', mo, mo'}
+          const f32x2 bb = tabb[(d * 2 + jp) * C16 + c16];
+          const f32x2 m2 = f32x2{mm.x, mm.y}, mo2 = f32x2{mm.z, mm.w};
+          f32x2 rA = f32x2{(float)sA[0], (float)sA[1]} * m2, rB = f32x2{(float)sB[0], (float)sB[1]} * m2;
+          if constexpr (FAST == 1) {
+            rA = rA + f32x2{(float)zA[0], (float)zA[1]} * mo2;
+            rB = rB + f32x2{(float)zB[0], (float)zB[1]} * mo2;
+          }
+          rA = rA + bb;            // (no bias: + 0, which only turns a -0 into +0 - the same code)
+          rB = rB + bb;
+          vA[2 * jp] = rA.x; vA[2 * jp + 1] = rA.y;
+          vB[2 * jp] = rB.x; vB[2 * jp + 1] = rB.y;
+        }
+        const f32x4 vv[2] = {vA, vB};
+        uint32_t ww[2];
+        eq.code4n_plain(vv, ww);
+        codesA[d] = ww[0];
+        codesB[d] = ww[1];
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32x4 ta = tabA[(d * 4 + j) * C16 + c16];
@@ -394,9 +473,14 @@ extern "C" int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* ou
     const int64_t qpairs = (Q + 1) / 2;
     g.qdiv = make_fastdiv((uint32_t)qpairs);
     const int64_t b16 = (N * P * qpairs * (C / 16) + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
-    hipLaunchKernelGGL(conv_dw3p2_i8_kernel, dim3((uint32_t)(b16 < 4096 ? b16 : 4096)), dim3(DLMCQ_BLOCK), (size_t)C * 48, st,
-                       static_cast<const u32x4*>(x), w, out, bias, in_scale, in_zero_point, w_scale, w_offset, g,
-                       x_is_unsigned ? 0 : 1, ep);
+    const int fast = (!out && epi_plain(ep)) ? (w_offset ? 1 : 2) : 0;
+#define DLMCQ_DWP2(F) hipLaunchKernelGGL(conv_dw3p2_i8_kernel<F>, dim3((uint32_t)(b16 < 4096 ? b16 : 4096)), dim3(DLMCQ_BLOCK), (size_t)C * 48, st, \
+                                         static_cast<const u32x4*>(x), w, out, bias, in_scale, in_zero_point, w_scale, w_offset, g,              \
+                                         x_is_unsigned ? 0 : 1, ep)
+    if (fast == 1) DLMCQ_DWP2(1);
+    else if (fast == 2) DLMCQ_DWP2(2);
+    else DLMCQ_DWP2(0);
+#undef DLMCQ_DWP2
   } else if (wide) {
     g.cdiv = make_fastdiv((uint32_t)(C / 16));
     const int64_t b16 = (N * P * Q * (C / 16) + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;

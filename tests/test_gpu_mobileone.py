@@ -86,7 +86,7 @@ def test_depthwise_kernel_shapes_and_forms():
         g = torch.Generator().manual_seed(40 + idx)
         lo, hi = (-127, 127) if signed else (0, 255)
         codes = torch.randint(lo, hi + 1, (n, c, h, w), generator=g).to(torch.int8 if signed else torch.uint8)
-        zp = 0.0 if signed else 4.0
+        zp = 0.0 if (signed or idx % 2) else 4.0      # (zero point 0: the two-pixel kernel reads its border taps as out-of-range buffer loads)
         qw = torch.randint(0, 16, (c, 1, r, r), generator=g)
         s_w = torch.rand(c, generator=g) * 0.02 + 0.001
         o_w = (torch.randn(c, generator=g) * 0.05) if asym else None
@@ -108,6 +108,19 @@ def test_depthwise_kernel_shapes_and_forms():
                                    bias.to(DEV), torch.tensor([s_in], device=DEV), torch.tensor([zp], device=DEV), s_w.to(DEV),
                                    None if o_w is None else o_w.to(DEV), stride=stride, padding=pad, relu=True, emit=emit, want_out=False)
         assert none is None and torch.equal(oc2, oc), f"dw case {idx} codes-only"
+        # the plain unsigned-byte quantiser (no zero point: every post-ReLU tensor of the frozen plans) takes the two-pixel kernel's
+        # pair-arithmetic path when only codes are wanted: the same bytes as the general path (fp32 output wanted as well), with and
+        # without a bias
+        plain = K.EmitCodes(emit.scale, None, 0, 255, N.FORM_ZEROPOINT)
+        for bb in (bias.to(DEV), None):
+            def run(want_out):
+                return K.conv2d_dw_i8(codes.to(DEV).contiguous(memory_format=torch.channels_last), qw[:, 0].permute(1, 2, 0).contiguous().to(torch.int8).to(DEV),
+                                      bb, torch.tensor([s_in], device=DEV), torch.tensor([zp], device=DEV), s_w.to(DEV),
+                                      None if o_w is None else o_w.to(DEV), stride=stride, padding=pad, relu=True, emit=plain, want_out=want_out)
+            out3, oc3 = run(True)
+            none, oc4 = run(False)
+            assert none is None and torch.equal(oc4, oc3), f"dw case {idx} plain quantiser, codes-only vs with fp32 output ({int((oc4 != oc3).sum())} differ)"
+            assert torch.equal(oc3.cpu().float(), O.fq_zeropoint(out3.cpu(), plain.scale.cpu(), torch.zeros(1), 0, 255)[0]), f"dw case {idx} plain codes"
 
 
 @pytest.mark.parametrize("c,k,r,stride,pad", [(3, 64, 3, 2, 1), (1, 32, 5, 1, 2), (4, 96, 7, 2, 3), (2, 8, 1, 1, 0)])
