@@ -25,6 +25,13 @@ __device__ __forceinline__ f32x4 bytes_s(uint32_t a) {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// the first v_dot4_i32_i8 of a chain in its three-address form: the compiler renders __builtin_amdgcn_sdot4 as the accumulating
+// v_dot4c_i32_i8, which needs a v_mov of the start value whenever that value is shared between chains (it always is here)
+__device__ __forceinline__ int dot4_from(uint32_t a, uint32_t b, int c) {
+  int d;
+  asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 constexpr int DW_BIG = 0x7fff0000;      // a byte offset beyond every tensor the buffer-addressed tap loads accept
 
 // 3 x 3, 16 channels per thread (C % 16 == 0): every tap is ONE 16-byte load per lane, all 9 taps requested before the first
@@ -174,10 +181,14 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4*
                                                                    DwGeom g, int x_signed, ConvEpi ep) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dw_lds[];
   const int C = g.C4 * 4, C16 = g.C4 >> 2;
-  u32x4* tabA = reinterpret_cast<u32x4*>(dw_lds);            // [16][C16]: {row 0, row 1, row 2 of pixel A's weights, dzw}
-  u32x4* tabB = tabA + C;                                    // [16][C16]: {rows of pixel B's weights (one byte up), -}
-  f32x4* tabp = reinterpret_cast<f32x4*>(tabB + C);          // [16][C16]: {m, mo, b, -};  FAST: [8][C16] {m, m', mo, mo'} of a channel PAIR,
-  f32x2* tabb = reinterpret_cast<f32x2*>(tabp + C / 2);      //                             then [8][C16] {b, b'} (zeros without a bias)
+  // Tables, one run of records per channel group (= per lane): a thread reads all its records at constant offsets from ONE base
+  // address (the round-3 layout [record][group] cost an address computation per read: ~2 of the kernel's ~26 vector instructions
+  // per element); the runs are padded to an odd number of 16-byte records so that neighbouring lanes start 4 banks apart.
+  constexpr int TS = 17, PS = 9;
+  u32x4* tabA = reinterpret_cast<u32x4*>(dw_lds);            // [C16][17]: {row 0, row 1, row 2 of pixel A's weights, dzw}
+  u32x4* tabB = tabA + C16 * TS;                             // [C16][17]: {rows of pixel B's weights (one byte up), -}
+  f32x4* tabp = reinterpret_cast<f32x4*>(tabB + C16 * TS);   // [C16][17]: {m, mo, b, -};  FAST: [C16][9] {m, m', mo, mo'} of a channel PAIR,
+  f32x2* tabb = reinterpret_cast<f32x2*>(tabp + C16 * PS);   //                            then [C16][9] {b, b'} (zeros without a bias)
   const float sin = s_in[0], zp = zp_in ? zp_in[0] : 0.0f;
   const int zpi = (int)zp;
   const int dz = (x_signed ? 0 : 128) - zpi;
@@ -195,11 +206,11 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4*
         ra[r] |= (uint32_t)(wv & 0xff) << (8 * s_);
       }
     }
-    const int slot = (c & 15) * C16 + (c >> 4);
+    const int slot = (c >> 4) * TS + (c & 15);
     tabA[slot] = u32x4{ra[0], ra[1], ra[2], (uint32_t)(dz * sum)};
     tabB[slot] = u32x4{ra[0] << 8, ra[1] << 8, ra[2] << 8, 0u};
     if constexpr (FAST) {
-      const int ps = ((c & 15) >> 1) * C16 + (c >> 4), e = c & 1;
+      const int ps = (c >> 4) * PS + ((c & 15) >> 1), e = c & 1;
       reinterpret_cast<float*>(tabp + ps)[e] = sin * s_w[c];
       reinterpret_cast<float*>(tabp + ps)[2 + e] = asym ? sin * o_w[c] : 0.0f;
       reinterpret_cast<float*>(tabb + ps)[e] = bias ? bias[c] : 0.0f;
@@ -211,6 +222,7 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4*
   const int64_t xbytes = (int64_t)g.N * g.H * g.W * C;
   const bool bufpath = zpi == 0 && xbytes < (int64_t)DW_BIG;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(x), 0, bufpath ? (int)xbytes : 0, 0x00020000);
+  const int dz9 = 9 * dz;
   const int QP = (g.Q + 1) >> 1;                             // pixel pairs per output row
   const int64_t total = (int64_t)g.N * g.P * QP * C16;
   const uint32_t zpw = (uint32_t)(zpi & 0xff) * 0x01010101u;
@@ -288,25 +300,25 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4*
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int j = 2 * jp + e;
-            const u32x4 ta = tabA[(d * 4 + j) * C16 + c16];
-            const u32x4 tb = tabB[(d * 4 + j) * C16 + c16];
-            sA[e] = __builtin_amdgcn_sdot4((int)Rw[0][j], (int)ta.x, (int)ta.w, false);
+            const u32x4 ta = tabA[c16 * TS + d * 4 + j];
+            const u32x4 tb = tabB[c16 * TS + d * 4 + j];
+            sA[e] = dot4_from(Rw[0][j], ta.x, (int)ta.w);
             sA[e] = __builtin_amdgcn_sdot4((int)Rw[1][j], (int)ta.y, sA[e], false);
             sA[e] = __builtin_amdgcn_sdot4((int)Rw[2][j], (int)ta.z, sA[e], false);
-            sB[e] = __builtin_amdgcn_sdot4((int)Rw[0][j], (int)tb.x, (int)ta.w, false);
+            sB[e] = dot4_from(Rw[0][j], tb.x, (int)ta.w);
             sB[e] = __builtin_amdgcn_sdot4((int)Rw[1][j], (int)tb.y, sB[e], false);
             sB[e] = __builtin_amdgcn_sdot4((int)Rw[2][j], (int)tb.z, sB[e], false);
             if constexpr (FAST == 1) {
-              zA[e] = __builtin_amdgcn_sdot4((int)Rw[0][j], 0x00010101, 9 * dz, false);
+              zA[e] = dot4_from(Rw[0][j], 0x00010101u, dz9);
               zA[e] = __builtin_amdgcn_sdot4((int)Rw[1][j], 0x00010101, zA[e], false);
               zA[e] = __builtin_amdgcn_sdot4((int)Rw[2][j], 0x00010101, zA[e], false);
-              zB[e] = __builtin_amdgcn_sdot4((int)Rw[0][j], 0x01010100, 9 * dz, false);
+              zB[e] = dot4_from(Rw[0][j], 0x01010100u, dz9);
               zB[e] = __builtin_amdgcn_sdot4((int)Rw[1][j], 0x01010100, zB[e], false);
               zB[e] = __builtin_amdgcn_sdot4((int)Rw[2][j], 0x01010100, zB[e], false);
             }
           }
-          const f32x4 mm = tabp[(d * 2 + jp) * C16 + c16];             // {m, m', mo, mo'}
-          const f32x2 bb = tabb[(d * 2 + jp) * C16 + c16];
+          const f32x4 mm = tabp[c16 * PS + d * 2 + jp];             // {m, m', mo, mo'}
+          const f32x2 bb = tabb[c16 * PS + d * 2 + jp];
           const f32x2 m2 = f32x2{mm.x, mm.y}, mo2 = f32x2{mm.z, mm.w};
           f32x2 rA = f32x2{(float)sA[0], (float)sA[1]} * m2, rB = f32x2{(float)sB[0], (float)sB[1]} * m2;
           if constexpr (FAST == 1) {
@@ -327,9 +339,9 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3p2_i8_kernel(const u32x4*
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const u32x4 ta = tabA[(d * 4 + j) * C16 + c16];
-        const u32x4 tb = tabB[(d * 4 + j) * C16 + c16];
-        const f32x4 tp = tabp[(d * 4 + j) * C16 + c16];
+        const u32x4 ta = tabA[c16 * TS + d * 4 + j];
+        const u32x4 tb = tabB[c16 * TS + d * 4 + j];
+        const f32x4 tp = tabp[c16 * TS + d * 4 + j];
         int sA = __builtin_amdgcn_sdot4((int)Rw[0][j], (int)ta.x, (int)ta.w, false);
         sA = __builtin_amdgcn_sdot4((int)Rw[1][j], (int)ta.y, sA, false);
         sA = __builtin_amdgcn_sdot4((int)Rw[2][j], (int)ta.z, sA, false);
@@ -474,7 +486,7 @@ extern "C" int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* ou
     g.qdiv = make_fastdiv((uint32_t)qpairs);
     const int64_t b16 = (N * P * qpairs * (C / 16) + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
     const int fast = (!out && epi_plain(ep)) ? (w_offset ? 1 : 2) : 0;
-#define DLMCQ_DWP2(F) hipLaunchKernelGGL(conv_dw3p2_i8_kernel<F>, dim3((uint32_t)(b16 < 4096 ? b16 : 4096)), dim3(DLMCQ_BLOCK), (size_t)C * 48, st, \
+#define DLMCQ_DWP2(F) hipLaunchKernelGGL(conv_dw3p2_i8_kernel<F>, dim3((uint32_t)(b16 < 4096 ? b16 : 4096)), dim3(DLMCQ_BLOCK), (size_t)(C / 16) * (3 * 17 * 16), st, \
                                          static_cast<const u32x4*>(x), w, out, bias, in_scale, in_zero_point, w_scale, w_offset, g,              \
                                          x_is_unsigned ? 0 : 1, ep)
     if (fast == 1) DLMCQ_DWP2(1);
