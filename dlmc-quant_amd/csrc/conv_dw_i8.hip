@@ -8,7 +8,7 @@
 //     EXACTLY (|S1| <= 9 * 255 * 255), so the arithmetic is the integer arithmetic of conv_i8.hip;
 //   * out = s_in * (s_w[c] * S1 + o_w[c] * S0) + bias[c]; asymmetric weights (w' = qw * s_w + o_w, ops.py:129-136) cost one
 //     more multiply-add per element; ReLU and the consumer's quantiser (conv_epilogue.h) follow in registers.
-#include "conv_epilogue.h"
+#include "conv_i8_common.h"
 
 namespace dlmcq {
 
@@ -479,6 +479,9 @@ extern "C" int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* ou
   const int64_t total = N * P * Q * (C / 4);
   const int64_t blocks = (total + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (conv_dwm_applies(N, H, W, C, R, S, stride, pad, ep, out, x))      // codes-only 3 x 3 / 1 / 1 layers: the multiply-adds on the matrix cores
+    return conv_dwm_launch(static_cast<const int8_t*>(x), w, bias, in_scale, in_zero_point, w_scale, w_offset, N, H, W, C,
+                           x_is_unsigned ? 0 : 1, ep, st);
   const bool wide = R == 3 && S == 3 && C % 16 == 0 && C <= 2048 && aligned16(x) && (!codes || aligned16(codes));
   if (wide && stride == 1 && pad == 1 && C <= 1024) {     // two output pixels per thread (LDS: 48 B per channel)
     g.cdiv = make_fastdiv((uint32_t)(C / 16));

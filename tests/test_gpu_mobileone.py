@@ -123,6 +123,51 @@ def test_depthwise_kernel_shapes_and_forms():
             assert torch.equal(oc3.cpu().float(), O.fq_zeropoint(out3.cpu(), plain.scale.cpu(), torch.zeros(1), 0, 255)[0]), f"dw case {idx} plain codes"
 
 
+@pytest.mark.parametrize("n,c,h,w,signed,asym,has_bias,zp", [
+    (8, 64, 28, 28, False, True, True, 0.0),        # 6 272 pixels, one chunk
+    (3, 192, 40, 37, False, True, True, 0.0),       # MobileOne-S1 stage 2's width, an odd image width
+    (2, 128, 56, 56, False, False, True, 3.0),      # the widest frame (57 positions per row), symmetric weights, a zero point
+    (24, 512, 14, 14, True, True, False, 0.0),      # stage 3: eight chunks, signed codes (no re-centring of the fragments), no bias
+    (5, 64, 33, 30, True, False, False, -7.0),
+])
+def test_depthwise_on_the_matrix_cores_is_the_vector_kernel_bit_for_bit(n, c, h, w, signed, asym, has_bias, zp):
+    """csrc/conv_dwm_i8.hip (3x3 / stride 1 / padding 1, codes only, the plain quantiser, >= 4 096 pixels) against
+    conv_dw3p2_i8_kernel (the same call on sub-batches below that size) and against a float64 convolution."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(n * 100 + c)
+    lo, hi = (-128, 127) if signed else (0, 255)
+    codes = torch.randint(lo, hi + 1, (n, c, h, w), generator=g).to(torch.int8 if signed else torch.uint8)
+    qw = torch.randint(0, 16, (c, 1, 3, 3), generator=g) if asym else torch.randint(-8, 8, (c, 1, 3, 3), generator=g)
+    s_w = torch.rand(c, generator=g) * 0.02 + 0.001
+    o_w = (torch.randn(c, generator=g) * 0.05) if asym else None
+    bias = torch.randn(c, generator=g) if has_bias else None
+    s_in = 0.03
+    xd = (codes.double() - zp) * s_in
+    wd = qw.double() * s_w.double().reshape(-1, 1, 1, 1) + (o_w.double().reshape(-1, 1, 1, 1) if asym else 0)
+    ref = torch.relu(F.conv2d(xd, wd, None if bias is None else bias.double(), padding=1, groups=c))
+    scale = torch.tensor([float(ref.max()) / 255 + 1e-3], device=DEV)
+    emit = K.EmitCodes(scale, None, 0, 255, N.FORM_ZEROPOINT)
+    cd = codes.to(DEV).contiguous(memory_format=torch.channels_last)
+    wq = qw[:, 0].permute(1, 2, 0).contiguous().to(torch.int8).to(DEV)
+
+    def run(x):
+        none, oc = K.conv2d_dw_i8(x, wq, None if bias is None else bias.to(DEV), torch.tensor([s_in], device=DEV), torch.tensor([zp], device=DEV),
+                                  s_w.to(DEV), None if o_w is None else o_w.to(DEV), stride=1, padding=1, relu=True, emit=emit, want_out=False)
+        assert none is None
+        return oc
+    assert n * h * w >= 4096
+    got = run(cd)
+    nsub = max(1, 4095 // (h * w))
+    for i0 in (0, n - nsub):            # the first and the last images through the vector kernel
+        sub = run(cd[i0:i0 + nsub].contiguous(memory_format=torch.channels_last))
+        assert torch.equal(got[i0:i0 + nsub], sub), f"{int((got[i0:i0 + nsub] != sub).sum())} codes differ from the vector kernel (images {i0}..)"
+    want = torch.clamp(torch.round(ref / float(scale)), 0, 255)
+    diff = (got.cpu().double() - want).abs()
+    assert float(diff.max()) <= 1.0 and float((diff > 0).double().mean()) < 2e-3, (float(diff.max()), float((diff > 0).double().mean()))
+
+
 @pytest.mark.parametrize("c,k,r,stride,pad", [(3, 64, 3, 2, 1), (1, 32, 5, 1, 2), (4, 96, 7, 2, 3), (2, 8, 1, 1, 0)])
 def test_asymmetric_first_layer_kernel(c, k, r, stride, pad):
     """dlmcq_conv2d_i8_stem_asym alone: every channel count the padded NHWC4 buffer allows, taps up to 7, against the float64
