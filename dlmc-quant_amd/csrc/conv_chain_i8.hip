@@ -301,7 +301,9 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   const int dz1b = DUALH ? a.shift2 - (int)__builtin_rintf(a.zp_in2 ? a.zp_in2[0] : 0.0f) : 0;
   ConvEpi e1 = ep1;
   e1.codes = reinterpret_cast<uint8_t*>(uintptr_t(1));   // the quantiser is always needed (GEMM 2 reads its codes)
-  const EpiQuant eq1(e1);
+  // FL >= 0 also says: both quantisers are the plain unsigned-byte one (epi_plain_q; the launcher checks) - code4n_plain, whose
+  // saturating pack is the ReLU as far as the codes are concerned
+  const EpiQuant eq1(e1, FL >= 0);
   __builtin_assume(!eq1.sgn);                            // (the range is [0, 255]: chain_launch refuses anything else)
 
   i32x16 acc2[U3];
@@ -401,11 +403,13 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
           y[k] = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
         }
         if constexpr (!DUALH) y[k] = y[k] + res[P][g];
-        if (relu1) y[k] = relu4_nan(y[k]);
+        if (relu1 && (FL < 0 || out1)) y[k] = relu4_nan(y[k]);      // (plain quantiser: only the fp32 output needs the rectified value)
         if (out1) bstore16(y[k], fo[g] + n * cstep, r_out);
       }
       uint32_t c[GP];
-      if constexpr (GP == 1) {
+      if constexpr (FL >= 0) {
+        eq1.code4n_plain(y, c);
+      } else if constexpr (GP == 1) {
         c[0] = eq1.code4(y[0]);
       } else {
         bool un[GP];
@@ -463,8 +467,12 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
                    dequant1(acc2[j][4 * q + 2] + co.z, mu.z, bs.z), dequant1(acc2[j][4 * q + 3] + co.w, mu.w, bs.w)};
     }
     uint32_t wq[4];
-    bool uq[4];
-    eq2.code4n(y, wq, uq);
+    if constexpr (FL >= 0) {
+      eq2.code4n_plain(y, wq);
+    } else {
+      bool uq[4];
+      eq2.code4n(y, wq, uq);
+    }
     if (lr2 < rows_here)
       *reinterpret_cast<i32x4*>(ep2.codes + (row0 + lr2) * KB + cb) = i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
   }
@@ -522,7 +530,7 @@ static int chain_launch(ChainArgs& a, int64_t M, int64_t C, int64_t K, int64_t C
   dyn = (g_chain_lab & 128 ? 40960 : 0) + (g_chain_lab & 256 ? 81920 : 0);   // timing only: unused dynamic LDS = fewer workgroups per CU
 #endif
   // the plan's launches end their first layer with a ReLU: those get the instantiation that knows its flags at compile time
-  const int fl = relu ? (a.out ? 3 : 1) : -1;
+  const int fl = (relu && epi_plain_q(ep1) && epi_plain_q(ep2)) ? (a.out ? 3 : 1) : -1;
 #define DLMCQ_CHAIN_GO(...)                                                                                          \
   do {                                                                                                               \
     if (fl == 3) hipLaunchKernelGGL((conv_chain_i8_kernel<__VA_ARGS__, 3>), grid, block, dyn, st, a, ep1, ep2);       \

@@ -43,12 +43,15 @@ class _ActSpec:
         self.scale, self.zp, self.lo, self.hi, self.form, self.needs_g = scale, zp, int(lo), int(hi), form, needs_g
         self.key = (form, self.lo, self.hi, float(scale.reshape(-1)[0]), 0.0 if zp is None else float(zp.reshape(-1)[0]),
                     needs_g)
+        # what a PRODUCER is told: a zero point of 0 (every post-ReLU tensor) goes as "none" - the kernels' plain-quantiser paths
+        # (csrc/conv_epilogue.h epi_plain) key on the null pointer (read once, when the plan is built)
+        self.zp_emit = None if self.key[4] == 0.0 else zp
 
     def g(self, numel):
         return 1 / math.sqrt(numel * self.hi) if self.needs_g else 0.0
 
     def emit(self, numel):
-        return K.EmitCodes(self.scale, self.zp, self.lo, self.hi, self.form, self.g(numel))
+        return K.EmitCodes(self.scale, self.zp_emit, self.lo, self.hi, self.form, self.g(numel))
 
 
 def _byte_range(lo, hi):

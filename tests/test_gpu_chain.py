@@ -55,6 +55,25 @@ def test_chain_matches_two_calls(c, k, k2, rows):
     assert torch.equal(out.view(torch.int32), out_r.view(torch.int32)) and torch.equal(codes, codes_r) and torch.equal(codes2, codes2_r)
 
 
+@pytest.mark.parametrize("c,k,k2", [(64, 256, 64), (64, 256, 128), (128, 512, 128), (128, 512, 256), (256, 1024, 256)])
+def test_chain_plain_quantisers_give_the_same_bytes(c, k, k2):
+    """Both quantisers unsigned bytes without a zero point (what the frozen plans pass for post-ReLU tensors: a null pointer): the
+    kernel's compile-time path (EpiQuant::code4n_plain, the pack's saturation as clamp and ReLU) against the general path (the
+    same quantisers with a zero point TENSOR of 0) and against the two separate calls."""
+    from dlmc import _native as N
+    n, h = 5, 14
+    K, a, b, res, emit, emit2 = _case(n, h, c, k, k2, seed=3 * c + k2, zp1=0.0, zp2=0.0)
+    plain, plain2 = K.EmitCodes(emit.scale, None, 0, 255, N.FORM_ZEROPOINT), K.EmitCodes(emit2.scale, None, 0, 255, N.FORM_ZEROPOINT)
+    out_r, codes_r, codes2_r = _reference(K, a, b, res, emit, emit2)
+    for want_out, want_codes in ((True, True), (False, True), (True, False)):
+        out, codes, codes2 = K.conv2d_i8_chain(a, b, res, relu=True, emit=plain, want_out=want_out, want_codes=want_codes, relu2=True, emit2=plain2)
+        if want_out:
+            assert torch.equal(out.view(torch.int32), out_r.view(torch.int32))
+        if want_codes:
+            assert torch.equal(codes, codes_r)
+        assert torch.equal(codes2, codes2_r)
+
+
 def test_chain_larger_batch_and_nonzero_zero_points():
     K, a, b, res, emit, emit2 = _case(64, 28, 128, 512, 128, seed=7, zp1=0.0, zp2=5.0)
     out_r, codes_r, codes2_r = _reference(K, a, b, res, emit, emit2)
