@@ -36,8 +36,8 @@ static inline bool epi_set_form(ConvEpi& ep, int32_t q_form, int32_t q_lo, int32
 }
 
 // the quantiser of every post-ReLU tensor in the frozen plans: unsigned byte range, no zero point (EpiQuant::code4n<N, true>)
-static inline bool epi_plain_q(const ConvEpi& ep) { return !ep.q_zp && ep.q_lo == 0.0f && ep.q_hi == 255.0f; }      // (the quantiser alone)
-static inline bool epi_plain(const ConvEpi& ep) { return ep.codes && epi_plain_q(ep); }
+__host__ __device__ static inline bool epi_plain_q(const ConvEpi& ep) { return !ep.q_zp && ep.q_lo == 0.0f && ep.q_hi == 255.0f; }      // (the quantiser alone)
+__host__ __device__ static inline bool epi_plain(const ConvEpi& ep) { return ep.codes && epi_plain_q(ep); }
 
 
 // The one rounding chain of every int8 kernel: exact integer sum -> fp32, then ONE fused multiply-add with the layer's

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
   const int zpi = (int)__builtin_rintf(zpf);
   const float sin = s_in[0];
   const EpiQuant eq(ep, SWAP && ep.relu);
+  const bool plainq = epi_plain(ep);         // unsigned bytes, no zero point: EpiQuant::code4n_plain (one uniform branch per 16 channels)
 
   // weights of this slab: fragment (r, j) = 16 bytes of channel n0 + j*32 + (lane & 31), taps hsel*4 .. +3
   // (SWAP: row d of a block is channel 16 ((d >> 2) & 1) + 4 (d >> 3) + (d & 3): accumulator register i = channel 16 hsel + i)
@@ -238,9 +239,22 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
     fetch(tile + (int)gridDim.x * 4, afn);
     i32x16 acc[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (SWAP) {      // the accumulators start from the zero-point term of their channels (four LDS reads instead of 16 additions)
+        const i32x4* cop = reinterpret_cast<const i32x4*>(ctab + 64 + j * 32 + hsel * 16);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[j][i] = 0;
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const i32x4 c4 = cop[q4];
+          acc[j][4 * q4] = c4.x;
+          acc[j][4 * q4 + 1] = c4.y;
+          acc[j][4 * q4 + 2] = c4.z;
+          acc[j][4 * q4 + 3] = c4.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0;
+      }
+    }
     int s0 = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -258,32 +272,38 @@ __global__ __launch_bounds__(256) void conv_stem_i8_kernel(const uint8_t* __rest
     }
     if constexpr (SWAP) {
       // lane (p = lane & 31, hsel): channels n0 + 32 j + 16 hsel + 0..15 of pixel m0 + p
-      float s0f = 0.0f;
+      f32x2 s0f2 = f32x2{0.0f, 0.0f};
       if (ASYM) {
         s0 += __shfl_xor(s0, 32, 64);
         s0 += (shift - zpi) * (R * g.S * g.C);
-        s0f = (float)s0;
+        s0f2 = f32x2{(float)s0, (float)s0};
       }
       uint8_t* cst = reinterpret_cast<uint8_t*>(stg);       // this wave's stage: 32 rows x 80 bytes of codes
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int cb = j * 32 + hsel * 16;
+        // the chain (sum * scale) + bias (+ sum of codes * offset) on PAIRS of channels: v_pk_mul_f32 / v_pk_add_f32, the same roundings
         f32x4 y[4];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
           const f32x4 mu = *reinterpret_cast<const f32x4*>(ctab + cb + 4 * q4);
-          const i32x4 co = *reinterpret_cast<const i32x4*>(ctab + 64 + cb + 4 * q4);
           const f32x4 bs = *reinterpret_cast<const f32x4*>(ctab + 128 + cb + 4 * q4);
-          y[q4] = f32x4{(float)(acc[j][4 * q4] + co.x) * mu.x + bs.x, (float)(acc[j][4 * q4 + 1] + co.y) * mu.y + bs.y,
-                        (float)(acc[j][4 * q4 + 2] + co.z) * mu.z + bs.z, (float)(acc[j][4 * q4 + 3] + co.w) * mu.w + bs.w};
+          f32x2 ya = f32x2{(float)acc[j][4 * q4], (float)acc[j][4 * q4 + 1]} * f32x2{mu.x, mu.y} + f32x2{bs.x, bs.y};
+          f32x2 yb = f32x2{(float)acc[j][4 * q4 + 2], (float)acc[j][4 * q4 + 3]} * f32x2{mu.z, mu.w} + f32x2{bs.z, bs.w};
           if (ASYM) {
             const f32x4 wo = *reinterpret_cast<const f32x4*>(ctab + 192 + cb + 4 * q4);
-            y[q4] = f32x4{y[q4].x + s0f * wo.x, y[q4].y + s0f * wo.y, y[q4].z + s0f * wo.z, y[q4].w + s0f * wo.w};
+            ya = ya + s0f2 * f32x2{wo.x, wo.y};
+            yb = yb + s0f2 * f32x2{wo.z, wo.w};
           }
+          y[q4] = f32x4{ya.x, ya.y, yb.x, yb.y};
         }
         uint32_t wq[4];
-        bool uq[4];
-        eq.code4n(y, wq, uq);
+        if (plainq) {
+          eq.code4n_plain(y, wq);
+        } else {
+          bool uq[4];
+          eq.code4n(y, wq, uq);
+        }
         *reinterpret_cast<i32x4*>(cst + (lane & 31) * 80 + cb) = i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave reads back only what it wrote itself
