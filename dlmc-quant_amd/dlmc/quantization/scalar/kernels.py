@@ -524,7 +524,11 @@ def conv2d_dw_i8(codes, wq, bias, in_scale, in_zp, w_scale, w_offset=None, strid
         q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, codes).reshape(-1)
         lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
     oe = n * c * P * Q
-    PROFILE.launch("conv_dw", codes.numel() + wq.numel() + oe * (4 * want_out + (emit is not None)),
+    # which kernel of the library takes the launch (conv_dwm_applies, csrc/conv_dwm_i8.hip: 3x3 / 1 / 1 codes-only layers with the plain
+    # quantiser on the matrix cores): the profile tag only
+    dwm = ((R, S) == (3, 3) and stride == 1 and padding == 1 and not want_out and emit is not None and emit.zero_point is None and
+           (emit.lo, emit.hi) == (0, 255) and c % 64 == 0 and 14 <= w_ <= 62 and n * h * w_ >= 4096 and n * h * w_ * c < 0x7fff0000)
+    PROFILE.launch("conv_dwm" if dwm else "conv_dw", codes.numel() + wq.numel() + oe * (4 * want_out + (emit is not None)),
                    lambda: N.check(N.lib.dlmcq_conv2d_dw_i8_nhwc(
                        N.ptr(codes), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale), N.ptr(w_offset),
                        n, h, w_, c, R, S, int(stride), int(padding), int(codes.dtype == torch.uint8), int(bool(relu)), N.ptr(out_codes),

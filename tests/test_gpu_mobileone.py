@@ -158,7 +158,16 @@ def test_depthwise_on_the_matrix_cores_is_the_vector_kernel_bit_for_bit(n, c, h,
         assert none is None
         return oc
     assert n * h * w >= 4096
-    got = run(cd)
+    K.PROFILE.reset()
+    K.PROFILE.enabled = True
+    try:
+        got = run(cd)
+        first = run(cd[:1].contiguous(memory_format=torch.channels_last))
+    finally:
+        K.PROFILE.enabled = False
+    assert [r[0] for r in K.PROFILE.records] == ["conv_dwm", "conv_dw"]      # (the profile tag follows the library's own dispatch rule)
+    K.PROFILE.reset()
+    assert torch.equal(got[:1], first)
     nsub = max(1, 4095 // (h * w))
     for i0 in (0, n - nsub):            # the first and the last images through the vector kernel
         sub = run(cd[i0:i0 + nsub].contiguous(memory_format=torch.channels_last))
