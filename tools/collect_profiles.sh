@@ -7,6 +7,10 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$GRAFT_REPO_ROOT/bench.py"
+# PART=1: bench lines, kernel stats, HBM traffic, plan profiles; PART=2: lab tools and counter passes; unset: everything (each part fits one
+# gpurun call of 20 minutes)
+PART=${PART:-all}
+if [ "$PART" = all ] || [ "$PART" = 1 ]; then
 python3 "$B" --steps 20 --warmup 5 > "$OUT/bench_line.json" 2> "$OUT/bench.err"
 python3 "$B" --steps 20 --warmup 5 --streams 1 --no-cpu-baseline > "$OUT/bench_line_streams1.json" 2>> "$OUT/bench.err"
 # per-kernel durations of the same command (one stream: rocprofv3 and the HIP events then describe the same thing)
@@ -21,6 +25,9 @@ python3 tools/plan_profile.py repvgg_a1 512 > "$OUT/plan_profile_repvgg_a1_b512.
 python3 tools/plan_profile.py mobileone_s1 1024 > "$OUT/plan_profile_mobileone_s1_b1024.txt" 2>&1
 python3 "$B" --model repvgg_a1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_line_repvgg_a1.json" 2>> "$OUT/bench.err"
 python3 "$B" --model mobileone_s1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_line_mobileone_s1.json" 2>> "$OUT/bench.err"
+find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
+fi
+if [ "$PART" = all ] || [ "$PART" = 2 ]; then
 # the halo-tile 3x3 kernel (round 3): ablations + per-workgroup clock stamps, and SQ / TCC counters of the kernel alone
 python3 tools/halo_lab.py --cases c1,c2,c3,c4 --generic --stamps > "$OUT/halo_lab_resnet50_3x3.txt" 2>&1
 bash tools/pmc_layer.sh "gpurun_out/prof_$R/pmc_c3_halo" c3 128:5 > /dev/null 2>&1 && cp "$OUT/pmc_c3_halo/summary.json" "$OUT/pmc_conv3x3_256_14.json" || echo "pmc c3 failed"
@@ -33,7 +40,15 @@ bash tools/pmc_chain_mem.sh "gpurun_out/prof_$R/pmc_chain_mem" s3,s2t,s1,s2 > /d
 python3 tools/chain_trace.py 512 64 56 256 64 > "$OUT/chain_trace_64_256_64_at_56.txt" 2>&1
 python3 tools/chain_trace.py 512 256 14 1024 256 > "$OUT/chain_trace_256_1024_256_at_14.txt" 2>&1
 python3 tools/conv_trace.py 512 256 14 256 3 > "$OUT/conv_trace_3x3_256_14.txt" 2>&1
+# round 4: the pointwise kernel beside the tiled one (ablations, one wave's stamps), its SQ counters, plan-wide instruction counters,
+# the vector-instruction issue-rate probe
+python3 tools/pw_lab.py --trace > "$OUT/pw_lab_mobileone_pointwise.txt" 2>&1
+bash tools/pmc_pw.sh "gpurun_out/prof_$R/pmc_pw" 192x28 > /dev/null 2>&1 && cp "$OUT/pmc_pw/summary.json" "$OUT/pmc_pointwise_192_28_sq.json" || echo "pmc pw failed"
+for mb in "resnet50 512" "repvgg_a1 512" "mobileone_s1 1024"; do set -- $mb; bash tools/pmc_plan.sh $1 $2 "gpurun_out/prof_$R/pmc_plan_$1" > "$OUT/pmc_plan_instruction_counts_$1.txt" 2>&1 || echo "pmc plan $1 failed"; done
+/opt/rocm/bin/hipcc -O2 -Wno-unused-value --offload-arch=gfx950 tools/probes/valu_probe.hip -o /tmp/valu_probe 2>/dev/null && timeout -k 5 60 /tmp/valu_probe > "$OUT/valu_issue_probe.txt" 2>&1 || echo "valu probe failed"
 python3 tools/kernel_bench.py > "$OUT/kernel_bench_config2.txt" 2>&1
 python3 tools/run_configs.py > "$OUT/configs_1_3_4_5.json" 2> "$OUT/configs.err"
-find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
+fi
+# the raw per-dispatch tables are large (gpurun copies at most 64 MiB back): the summaries above are what is kept
+find "$OUT" -mindepth 2 \( -name "*counter_collection.csv" -o -name "*kernel_trace.csv" -o -name "*agent_info.csv" \) -delete
 ls -la "$OUT"
