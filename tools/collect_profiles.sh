@@ -28,6 +28,7 @@ python3 "$B" --model mobileone_s1 --steps 20 --warmup 5 --no-cpu-baseline > "$OU
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
 fi
 if [ "$PART" = all ] || [ "$PART" = 2 ]; then
+cd "$GRAFT_REPO_ROOT"
 # the halo-tile 3x3 kernel (round 3): ablations + per-workgroup clock stamps, and SQ / TCC counters of the kernel alone
 python3 tools/halo_lab.py --cases c1,c2,c3,c4 --generic --stamps > "$OUT/halo_lab_resnet50_3x3.txt" 2>&1
 bash tools/pmc_layer.sh "gpurun_out/prof_$R/pmc_c3_halo" c3 128:5 > /dev/null 2>&1 && cp "$OUT/pmc_c3_halo/summary.json" "$OUT/pmc_conv3x3_256_14.json" || echo "pmc c3 failed"
