@@ -239,7 +239,7 @@ def side_config(name, batch, args, dev, world, rank, barrier):
         quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=True)
     g = torch.Generator(device=dev).manual_seed(2333 + rank)
     x = torch.relu(torch.randn(batch, 3, 224, 224, device=dev, generator=g))
-    steps, warmup = args.other_steps, 3
+    steps, warmup = args.other_steps, 10
     with torch.no_grad():
         model(x)                                      # calibration (observers + their all-reduce), untimed
         single = fuse_inference(model)
