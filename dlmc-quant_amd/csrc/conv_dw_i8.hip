@@ -25,6 +25,7 @@ __device__ __forceinline__ f32x4 bytes_s(uint32_t a) {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // the first v_dot4_i32_i8 of a chain in its three-address form: the compiler renders __builtin_amdgcn_sdot4 as the accumulating
 // v_dot4c_i32_i8, which needs a v_mov of the start value whenever that value is shared between chains (it always is here)
 __device__ __forceinline__ int dot4_from(uint32_t a, uint32_t b, int c) {
@@ -49,6 +50,10 @@ struct DwTab {       // per channel, in LDS: two 16-byte records, each stored [p
   uint32_t pad;
 };
 
+// FAST (round 4): 1 / 2 = codes-only layer with the plain quantiser, asymmetric / symmetric weights - what conv_dw3p2_i8_kernel<FAST> does for
+// stride 1 (the fp32 chain on channel pairs, all four quantiser quads behind one branch, border taps as out-of-range buffer loads
+// when the zero point is 0, table runs per lane), here for any stride (MobileOne's four stride-2 layers).  0 = everything else.
+template <int FAST>
 __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* __restrict__ x, const int8_t* __restrict__ w,
                                                                  float* __restrict__ out, const float* __restrict__ bias,
                                                                  const float* __restrict__ s_in, const float* __restrict__ zp_in,
@@ -56,12 +61,14 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
                                                                  DwGeom g, int x_signed, ConvEpi ep) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dw_lds[];
   const int C = g.C4 * 4, C16 = g.C4 >> 2;
-  u32x4* tabw = reinterpret_cast<u32x4*>(dw_lds);            // [16][C16]: {w0, w1, w2, dzw}
-  f32x4* tabp = reinterpret_cast<f32x4*>(dw_lds) + C;       // [16][C16]: {m, mo, b, -}
+  constexpr int TS = FAST ? 17 : 0, PS = 9;                  // FAST: one run of records per channel group (conv_dw3p2_i8_kernel)
+  u32x4* tabw = reinterpret_cast<u32x4*>(dw_lds);            // [16][C16]: {w0, w1, w2, dzw}                       FAST: [C16][17]
+  f32x4* tabp = reinterpret_cast<f32x4*>(dw_lds) + (FAST ? C16 * 17 : C);   // [16][C16]: {m, mo, b, -}          FAST: [C16][9] {m, m', mo, mo'} of a channel pair,
+  f32x2* tabb = reinterpret_cast<f32x2*>(tabp + C16 * PS);   //                                                          then [C16][9] {b, b'}
   const float sin = s_in[0], zp = zp_in ? zp_in[0] : 0.0f;
   const int zpi = (int)zp;
   const int dz = (x_signed ? 0 : 128) - zpi;
-  const bool asym = o_w != nullptr;
+  const bool asym = FAST ? FAST == 1 : o_w != nullptr;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     uint32_t pk[3] = {0u, 0u, 0u};
     int sum = 0;
@@ -71,12 +78,24 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
       sum += wv;
       pk[k >> 2] |= (uint32_t)(wv & 0xff) << (8 * (k & 3));
     }
-    const int slot = (c & 15) * C16 + (c >> 4);
-    tabw[slot] = u32x4{pk[0], pk[1], pk[2], (uint32_t)(dz * sum)};
-    tabp[slot] = f32x4{sin * s_w[c], asym ? sin * o_w[c] : 0.0f, bias ? bias[c] : 0.0f, 0.0f};
+    if constexpr (FAST != 0) {
+      tabw[(c >> 4) * TS + (c & 15)] = u32x4{pk[0], pk[1], pk[2], (uint32_t)(dz * sum)};
+      const int ps = (c >> 4) * PS + ((c & 15) >> 1), e = c & 1;
+      reinterpret_cast<float*>(tabp + ps)[e] = sin * s_w[c];
+      reinterpret_cast<float*>(tabp + ps)[2 + e] = asym ? sin * o_w[c] : 0.0f;
+      reinterpret_cast<float*>(tabb + ps)[e] = bias ? bias[c] : 0.0f;
+    } else {
+      const int slot = (c & 15) * C16 + (c >> 4);
+      tabw[slot] = u32x4{pk[0], pk[1], pk[2], (uint32_t)(dz * sum)};
+      tabp[slot] = f32x4{sin * s_w[c], asym ? sin * o_w[c] : 0.0f, bias ? bias[c] : 0.0f, 0.0f};
+    }
   }
   __syncthreads();
   const int64_t total = (int64_t)g.N * g.P * g.Q * C16;
+  const int64_t xbytes = (int64_t)g.N * g.H * g.W * C;
+  const bool bufpath = FAST != 0 && zpi == 0 && xbytes < (int64_t)DW_BIG;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(x), 0, bufpath ? (int)xbytes : 0, 0x00020000);
+  const int dz9 = 9 * dz;
   const uint32_t zpw = (uint32_t)(zpi & 0xff) * 0x01010101u;
   const uint32_t xw = x_signed ? 0u : 0x80808080u;
   // codes-only layers: the ReLU is folded into the quantiser's clamp (code(relu(v)) = max(code(v), code(0)): conv_epilogue.h)
@@ -93,7 +112,19 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
     u32x4 a[9];
     const u32x4* img = x + (int64_t)n * g.H * g.W * C16 + c16;
     const bool inside = h0 >= 0 && w0 >= 0 && h0 + 2 < g.H && w0 + 2 < g.W;
-    if (__builtin_amdgcn_ballot_w64(!inside) == 0) {      // the whole wave is away from the image border (almost always): no checks
+    if (bufpath) {                                        // (conv_dw3p2_i8_kernel: a tap outside the image reads beyond the tensor's end = zeros = the zero point)
+      const int base0 = (int)(((uint32_t)n * (uint32_t)g.H + (uint32_t)h0) * (uint32_t)g.W + (uint32_t)w0) * C + c16 * 16;
+      bool cok[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) cok[s] = (uint32_t)(w0 + s) < (uint32_t)g.W;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const bool rok = (uint32_t)(h0 + r) < (uint32_t)g.H;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          a[r * 3 + s] = __builtin_amdgcn_raw_buffer_load_b128(rx, (rok && cok[s]) ? base0 + (r * g.W + s) * C : DW_BIG, 0, 0) ^ xw;
+      }
+    } else if (__builtin_amdgcn_ballot_w64(!inside) == 0) {      // the whole wave is away from the image border (almost always): no checks
       const u32x4* p0 = img + ((int64_t)h0 * g.W + w0) * C16;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
@@ -113,6 +144,7 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
     }
     const int c = c16 * 16;
     uint32_t codes[4];
+    f32x4 vq[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {                                   // 4 channels at a time
       // bytes of a[k][d]: channels c + 4d .. + 3 of tap k.  Transposed: T[j] = taps 0-3, U[j] = taps 4-7, V[j] = tap 8 of channel j
@@ -136,6 +168,34 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
 #pragma unroll
       for (int j = 0; j < 4; ++j) V[j] = (a[8][d] >> (8 * j)) & 0xffu;
       f32x4 v;
+      if constexpr (FAST != 0) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {                               // channels c + 4d + 2jp, + 1
+          int s1[2], s0[2] = {0, 0};
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int j = 2 * jp + e;
+            const u32x4 tw = tabw[c16 * TS + d * 4 + j];
+            s1[e] = dot4_from(T[j], tw.x, (int)tw.w);
+            s1[e] = __builtin_amdgcn_sdot4((int)U[j], (int)tw.y, s1[e], false);
+            s1[e] = __builtin_amdgcn_sdot4((int)V[j], (int)tw.z, s1[e], false);
+            if constexpr (FAST == 1) {
+              s0[e] = dot4_from(T[j], 0x01010101u, dz9);
+              s0[e] = __builtin_amdgcn_sdot4((int)U[j], 0x01010101, s0[e], false);
+              s0[e] = __builtin_amdgcn_sdot4((int)V[j], 0x01010101, s0[e], false);
+            }
+          }
+          const f32x4 mm = tabp[c16 * PS + d * 2 + jp];                // {m, m', mo, mo'}
+          const f32x2 bb = tabb[c16 * PS + d * 2 + jp];
+          f32x2 r = f32x2{(float)s1[0], (float)s1[1]} * f32x2{mm.x, mm.y};
+          if constexpr (FAST == 1) r = r + f32x2{(float)s0[0], (float)s0[1]} * f32x2{mm.z, mm.w};
+          r = r + bb;                                                   // (no bias: + 0 - the same code)
+          v[2 * jp] = r.x;
+          v[2 * jp + 1] = r.y;
+        }
+        vq[d] = v;
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32x4 tw = tabw[(d * 4 + j) * C16 + c16];
@@ -158,6 +218,7 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void conv_dw3_i8_kernel(const u32x4* _
       if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
       if (ep.codes) codes[d] = eq.code4(v);
     }
+    if constexpr (FAST != 0) eq.code4n_plain(vq, codes);
     if (ep.codes) __builtin_nontemporal_store(u32x4{codes[0], codes[1], codes[2], codes[3]},
                                               reinterpret_cast<u32x4*>(ep.codes + (int64_t)pix * g.C4 * 4 + c));
   }
@@ -500,9 +561,14 @@ extern "C" int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* ou
     g.cdiv = make_fastdiv((uint32_t)(C / 16));
     const int64_t b16 = (N * P * Q * (C / 16) + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
     // every workgroup packs the layer's weights into its LDS table first: a grid of a few workgroups per CU, each walking many pixels
-    hipLaunchKernelGGL(conv_dw3_i8_kernel, dim3((uint32_t)(b16 < 4096 ? b16 : 4096)), dim3(DLMCQ_BLOCK), (size_t)C * sizeof(DwTab), st,
-                       static_cast<const u32x4*>(x), w, out, bias, in_scale, in_zero_point, w_scale, w_offset, g,
-                       x_is_unsigned ? 0 : 1, ep);
+    const int fast = (!out && epi_plain(ep)) ? (w_offset ? 1 : 2) : 0;
+#define DLMCQ_DW3(F) hipLaunchKernelGGL(conv_dw3_i8_kernel<F>, dim3((uint32_t)(b16 < 4096 ? b16 : 4096)), dim3(DLMCQ_BLOCK),                 \
+                                        F ? (size_t)(C / 16) * (17 * 16 + 9 * 16 + 9 * 8) : (size_t)C * sizeof(DwTab), st, static_cast<const u32x4*>(x), w, \
+                                        out, bias, in_scale, in_zero_point, w_scale, w_offset, g, x_is_unsigned ? 0 : 1, ep)
+    if (fast == 1) DLMCQ_DW3(1);
+    else if (fast == 2) DLMCQ_DW3(2);
+    else DLMCQ_DW3(0);
+#undef DLMCQ_DW3
   } else {
     hipLaunchKernelGGL(conv_dw_i8_kernel, dim3((uint32_t)(blocks < (1 << 20) ? blocks : (1 << 20))), dim3(DLMCQ_BLOCK), 0, st,
                        static_cast<const uint32_t*>(x), reinterpret_cast<const uint32_t*>(w), out, bias, in_scale, in_zero_point, w_scale,

@@ -82,7 +82,10 @@ def test_depthwise_kernel_shapes_and_forms():
                                                                       # the two-pixels-per-thread kernel (3x3, stride 1, padding 1, C % 16 == 0):
                                                                       # even / odd widths, a single column, signed codes, one row
                                                                       (1, 128, 5, 6, 3, 1, 1, False, False), (2, 32, 3, 1, 3, 1, 1, True, True),
-                                                                      (3, 16, 1, 7, 3, 1, 1, False, True), (1, 96 + 16, 28, 28, 3, 1, 1, False, True)]):
+                                                                      (3, 16, 1, 7, 3, 1, 1, False, True), (1, 96 + 16, 28, 28, 3, 1, 1, False, True),
+                                                                      # the one-pixel 16-channel kernel (3x3, C % 16 == 0, any stride / padding): MobileOne's stride-2 layers
+                                                                      (2, 64, 13, 12, 3, 2, 1, False, True), (2, 32, 9, 9, 3, 1, 0, False, False),
+                                                                      (1, 48, 8, 8, 3, 2, 1, True, True), (2, 16, 7, 9, 3, 2, 1, False, True)]):
         g = torch.Generator().manual_seed(40 + idx)
         lo, hi = (-127, 127) if signed else (0, 255)
         codes = torch.randint(lo, hi + 1, (n, c, h, w), generator=g).to(torch.int8 if signed else torch.uint8)
