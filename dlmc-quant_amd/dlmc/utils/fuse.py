@@ -349,7 +349,7 @@ class DwInt8Layer(Int8Layer):
         codes = self._codes(x)
         numel = self._real_numel(codes)
         emit = self._emit_for(codes.shape[0], self.k, *self._out_hw(codes))
-        res = K.conv2d_dw_i8(codes, self.wq, self._bias(), self._in_scale(numel), act.zp, self.w_scale, self.w_off,
+        res = K.conv2d_dw_i8(codes, self.wq, self._bias(), self._in_scale(numel), self._zp(codes), self.w_scale, self.w_off,
                              stride=lay.stride[0], padding=lay.padding[0], relu=self.relu, emit=emit, want_out=self.want_out)
         out, out_codes = res if emit is not None else (res, None)
         return self._finish(out, out_codes)
@@ -434,12 +434,12 @@ class DwPwInt8Layer(nn.Module):
         table = self._tables.get(key)
         if table is None:
             self._tables.clear()
-            table = self._tables[key] = K.dwpw_table(dw.wq, dw._bias(), dw._in_scale(numel), dw.act.zp, dw.w_scale, dw.w_off,
+            table = self._tables[key] = K.dwpw_table(dw.wq, dw._bias(), dw._in_scale(numel), dw._zp(codes), dw.w_scale, dw.w_off,
                                                      x_unsigned=codes.dtype == torch.uint8)
         emit = dw._emit_for(n, dw.k, h, w)                          # the depthwise output's quantiser = the pointwise layer's input quantiser
         emit2 = pw._emit_for(n, pw.layer.weight.shape[0], h, w)
         op = dict(wq=pw.wq, wsum=pw.wsum, bias=pw._bias(), w_scale=pw.w_scale, w_offset=pw.w_off, in_scale=pw._in_scale(n * h * w * pw.c))
-        out = K.conv2d_dwpw_i8(codes, table, dw.w_off is not None, dw._bias() is not None, dw.relu, dw.act.zp, emit, op, relu=pw.relu, emit2=emit2)
+        out = K.conv2d_dwpw_i8(codes, table, dw.w_off is not None, dw._bias() is not None, dw.relu, dw._zp(codes), emit, op, relu=pw.relu, emit2=emit2)
         return pw._finish(None, out)
 
 
@@ -981,8 +981,12 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int
             def takes_shifted(u):
                 sp = spec_of(u) if u.op == "call_module" else None
                 m = modules.get(u.target) if u.op == "call_module" else None
-                return (sp is not None and sp[4] == "gemm" and m is not None and m.weight.dim() == 4 and m.groups == 1 and
-                        m.weight.shape[1] % 64 == 0)
+                if sp is None or m is None or m.weight.dim() != 4:
+                    return False
+                if sp[4] == "dw":      # the matrix-core depthwise kernel (csrc/conv_dwm_i8.hip) multiplies signed bytes: no re-centring of its fragments
+                    # (not with `dwpw`: the fused unit's kernel emits plain codes only)
+                    return (not dwpw and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.weight.shape[0] % 64 == 0)
+                return sp[4] == "gemm" and m.groups == 1 and m.weight.shape[1] % 64 == 0
             plan.emit_shift = bool(cls is Int8Layer and emit is not None and 0 <= emit.lo and emit.hi <= 255 and pool is None and
                                    plan.k_pad == plan.k and takers and all(takes_shifted(u) for u in takers))
             gm.add_module(name, DualInt8Layer(plan, Int8Layer(modules[residual.target], other)) if dual else plan)
