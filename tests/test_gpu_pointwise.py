@@ -92,6 +92,31 @@ def test_pointwise_kernel_is_the_tiled_kernel_bit_for_bit(case):
     assert float(diff.max()) <= 1.0 and float((diff > 0).double().mean()) < 1e-3, (float(diff.max()), float((diff > 0).double().mean()))
 
 
+def test_pointwise_kernel_emits_recentred_codes_like_the_tiled_kernel():
+    """DLMCQ_EMIT_SHIFT128 (codes handed to a matrix-core consumer as int8 `code - 128`: what MobileOne's pointwise layers now emit for
+    the depthwise layers behind them): the same bytes from both kernels, and `code - 128` of the plain emission."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator(device=DEV).manual_seed(77)
+    n, h, w, c, k = 12, 20, 20, 192, 192
+    codes = torch.randint(0, 256, (n, c, h, w), generator=g, device=DEV, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+    wq = torch.randint(0, 16, (k, 1, 1, c), generator=g, device=DEV, dtype=torch.int8)
+    wsum = wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
+    s_w = (torch.rand(k, generator=g, device=DEV) * 0.004 + 0.0005).contiguous()
+    w_off = (torch.randn(k, generator=g, device=DEV) * 0.01).contiguous()
+    bias = torch.randn(k, generator=g, device=DEV)
+    s_in = torch.full((1,), 0.021, device=DEV)
+    q_scale = torch.full((1,), 0.043, device=DEV)
+
+    def run(cd, shifted):
+        emit = K.EmitCodes(q_scale, None, 0, 255, N.FORM_ZEROPOINT, shift128=shifted)
+        return K.conv2d_i8(cd, wq, wsum, bias, s_in, None, s_w, relu=True, emit=emit, want_out=False, w_offset=w_off)[1]
+    plain, shifted = run(codes, False), run(codes, True)
+    assert shifted.dtype == torch.int8 and torch.equal(shifted.to(torch.int16) + 128, plain.to(torch.int16))
+    sub = run(codes[:9].contiguous(memory_format=torch.channels_last), True)          # 3 600 pixels: the tiled kernel
+    assert torch.equal(shifted[:9], sub)
+
+
 def test_pointwise_kernel_leaves_the_rest_to_the_tiled_kernel():
     """Shapes outside its list (other widths, strides, an fp32 output, a shortcut) take the tiled kernel as before."""
     from dlmc import _native as N
