@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
     }
   };
   const EpiQuant eq(ep, ep.relu != 0);                     // code(relu(v)) = max(code(v), code(0))
+  const bool plainq = epi_plain(ep);                       // unsigned bytes, no zero point: EpiQuant::code4n_plain
 
   // ---- prologue: rows 4 p0 - 3 .. 4 p0 + 8 (three groups), then the upper row of the first window ----
   issue_group(p0 - 2);
@@ -252,8 +253,12 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
                       (float)(a[3] + co.w) * mu.w + bs.w};
       }
       uint32_t wq[4];
-      bool uq[4];
-      eq.code4n(y, wq, uq);
+      if (plainq) {
+        eq.code4n_plain(y, wq);
+      } else {
+        bool uq[4];
+        eq.code4n(y, wq, uq);
+      }
       // 16-byte unit u = 2 j + hsel of pixel l31 goes to slot u ^ ((l31 >> 2) & 3) of its 64-byte row (conflict-free both ways)
       *reinterpret_cast<i32x4*>(stg + l31 * 64 + (((2 * j + hsel) ^ ((l31 >> 2) & 3)) << 4)) = i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
     }
