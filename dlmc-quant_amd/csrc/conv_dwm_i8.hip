@@ -166,12 +166,7 @@ __global__ __launch_bounds__(256, 3) void conv_dwm_i8_kernel(DwmArgs a, ConvEpi 
         for (int e = 0; e < 2; ++e) {
           const i32x4 t = *reinterpret_cast<const i32x4*>(hb + foff[k] + (2 * bp + e) * 2048);
           const i32x4 bf = XS ? t : i32x4{(int)(t.x ^ xw), (int)(t.y ^ xw), (int)(t.z ^ xw), (int)(t.w ^ xw)};
-#if defined(DWM_X) && DWM_X == 2
-          asm volatile("" ::"v"(bf));
-          if (k == 0) acc[e] = init;
-#else
           acc[e] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wfrag[k], bf, k == 0 ? init : acc[e], 0, 0, 0);
-#endif
         }
       }
 #pragma unroll
@@ -187,12 +182,7 @@ __global__ __launch_bounds__(256, 3) void conv_dwm_i8_kernel(DwmArgs a, ConvEpi 
           v[jp >> 1][2 * (jp & 1) + 1] = r.y;
         }
         uint32_t wq[2];
-#if defined(DWM_X) && DWM_X == 4
-        wq[0] = (uint32_t)acc[e][0]; wq[1] = (uint32_t)acc[e][8];
-        asm volatile("" ::"v"(v[0]), "v"(v[1]));
-#else
         eq.code4n_plain(v, wq);
-#endif
         *reinterpret_cast<uint2*>(stage + ((2 * bp + e) * 32 + l31) * 64 + wave * 16 + hsel * 8) = uint2{wq[0], wq[1]};
       }
     }
@@ -217,11 +207,7 @@ __global__ __launch_bounds__(256, 3) void conv_dwm_i8_kernel(DwmArgs a, ConvEpi 
       const bool next = wrap && fy0 == (uint32_t)a.H;
       const uint32_t fy = next ? 0u : fy0 + (wrap ? 1u : 0u);
       const uint32_t nn = n0 + (next ? 1u : 0u);
-#if defined(DWM_X) && DWM_X == 1
-      const bool ok = n0 == 0xffffffffu;
-#else
       const bool ok = nn < (uint32_t)a.N && fy < (uint32_t)a.H && fx < (uint32_t)a.W;
-#endif
       const int pix = pix0 + lrow - (wrap ? 1 : 0) - (next ? a.W : 0);
       const i32x4 c16 = *reinterpret_cast<const i32x4*>(stage + (it * 64 + wave_u * 16 + lrow) * 64 + sseg * 16);
       bstore16i(c16, ok ? pix * a.C + chunk * 64 + sseg * 16 : BUF_BIG, r_c);
