@@ -15,12 +15,14 @@
 // so five instructions (nine taps in pairs) give a lane BOTH sums of 8 channels of one position, already in the accumulator
 // registers; the zero-point terms ((shift - zp) SUM w, 9 (shift - zp)) are the accumulators' start values (the C operand of the
 // first instruction: no vector instruction).  What is left for the vector unit: 2 conversions, the fp32 chain on pairs and the
-// plain quantiser (EpiQuant::code4n_plain) - ~9 instructions per element.
+// plain quantiser (EpiQuant::code4n_plain) - 8 instructions per element in the blocks (10.75 with unsigned input codes, whose
+// fragments are re-centred), 16 measured over the whole kernel with the frame arithmetic of requests and stores.
 //
 // Structure: the linear frame of conv3x3_i8.hip / conv_dwpw_i8.hip (image n as (H + 1) x (W + 1) positions with shared
 // zero-point borders: the nine taps are nine fixed shifts of one sequence).  A workgroup owns ONE 64-channel chunk - its four
 // waves one 16-channel segment each, weights and constants in registers for the whole launch - and walks tiles of 128 positions:
-// halo tile by LDS-DMA (double-buffered: the next tile's is requested before this tile's arithmetic), fragments by ds_read_b128,
+// halo tiles by LDS-DMA (three buffers: the tile after next is requested before this tile's arithmetic; counted waits), two blocks'
+// MFMA chains interleaved (five dependent instructions per block otherwise), fragments by ds_read_b128 at constant offsets,
 // codes through an LDS stage so that a position's 64 bytes leave together.  Same integers, same fp32 chain, same quantiser as
 // conv_dw3p2_i8_kernel: bit-identical (tests/test_gpu_mobileone.py).
 #include "conv_i8_common.h"

@@ -2,19 +2,22 @@
 // (modules/conv.py:13-19 on FSPTQuant/base.py:108-109 / ops.py:129-136 operands; MobileOne-S1's 21 pointwise layers, BASELINE
 // configs[4]).
 //
-// Why a kernel of its own (tools/pw_lab.py, round 4): on these layers the reduction is 1-8 K steps long and the tiled kernel of
+// Why a kernel of its own (tools/pw_lab.py, LABNOTES 12): on these layers the reduction is 1-8 K steps long and the tiled kernel of
 // conv_i8.hip spends its time in three phases that ADD UP - a tile's operand round trip (weights re-streamed per tile: 37 KB of
-// weights for 25 KB of activations at 192 -> 192), its quantising epilogue (25-50 % of the kernel, one wave issues a vector
-// instruction every ~5 clocks, a SIMD could take one every ~2.5 from several waves) and its staged stores -, with a barrier per
-// K step keeping the four waves of a workgroup in the same phase.  Here
+// weights for 25 KB of activations at 192 -> 192), its quantising epilogue (25-50 % of the kernel: a wave64 vector instruction
+// occupies its SIMD for 4 clocks whatever it is) and its staged stores -, with a barrier per K step keeping the four waves of a
+// workgroup in the same phase.  Here
 //   * a workgroup loads its slice of the weights (BN output channels x C bytes, LDS-DMA, conv_i8.hip's swizzled 64-byte rows)
 //     and the per-channel constants ONCE and then never synchronises again: no ring, no barrier in the loop;
 //   * every wave walks blocks of 32 pixels on its own: activation fragments straight to registers (buffer loads, the NEXT
-//     block's requested before this block's epilogue, so the epilogue runs in the shadow of the loads), C / 32 x BN / 32 MFMAs
-//     with the weights as the A operand (swapped layout: a lane owns 16 consecutive output channels of one pixel), the swapped
-//     epilogue of conv_i8.hip operation for operation, 16-byte stores straight from the registers;
+//     block's requested in the middle of this block's epilogue behind a counted wait, so the epilogue runs in the shadow of the
+//     loads), C / 32 x BN / 32 MFMAs with the weights as the A operand (swapped layout: a lane owns 16 consecutive output channels
+//     of one pixel) in passes of NTP accumulator blocks, the swapped epilogue of conv_i8.hip on channel pairs with the plain
+//     quantiser (conv_epilogue.h: code4n_plain; the launcher checks epi_plain), the codes through a wave-private LDS stage so
+//     that the stores are whole rows (32-byte pieces straight from the accumulator layout cost as much as all the rest);
 //   * waves drift apart freely, so one wave's vector arithmetic overlaps another's matrix and memory work.
-// Same integers, same fp32 chain, same quantiser as conv_i8_mfma_kernel: bit-identical (tests/test_gpu_pointwise.py).
+// Same integers, same fp32 chain, the same bytes as conv_i8_mfma_kernel (tests/test_gpu_pointwise.py).  tools/lint_pw.py checks
+// the listing: no scratch, nothing touches a fragment register between its load and the counted wait (control-flow walk).
 #include "conv_i8_common.h"
 
 namespace dlmcq {
