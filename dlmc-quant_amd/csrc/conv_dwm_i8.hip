@@ -185,7 +185,12 @@ __global__ __launch_bounds__(256, 3) void conv_dwm_i8_kernel(DwmArgs a, ConvEpi 
         }
         uint32_t wq[2];
         eq.code4n_plain(v, wq);
-        *reinterpret_cast<uint2*>(stage + ((2 * bp + e) * 32 + l31) * 64 + wave * 16 + hsel * 8) = uint2{wq[0], wq[1]};
+        // (16-byte segment s of position p sits in slot s ^ ((p >> 2) & 3), like the halo tiles: unswizzled, the 32 positions of a
+        //  block write through 8 banks - SQ_LDS_BANK_CONFLICT was half of the kernel's LDS cycles)
+        {
+          const int ps = (2 * bp + e) * 32 + l31;
+          *reinterpret_cast<uint2*>(stage + ps * 64 + ((wave ^ ((ps >> 2) & 3)) << 4) + hsel * 8) = uint2{wq[0], wq[1]};
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the tile's codes are staged (a position's 64 bytes come from four waves)
@@ -211,7 +216,8 @@ __global__ __launch_bounds__(256, 3) void conv_dwm_i8_kernel(DwmArgs a, ConvEpi 
       const uint32_t nn = n0 + (next ? 1u : 0u);
       const bool ok = nn < (uint32_t)a.N && fy < (uint32_t)a.H && fx < (uint32_t)a.W;
       const int pix = pix0 + lrow - (wrap ? 1 : 0) - (next ? a.W : 0);
-      const i32x4 c16 = *reinterpret_cast<const i32x4*>(stage + (it * 64 + wave_u * 16 + lrow) * 64 + sseg * 16);
+      const int ps = it * 64 + wave_u * 16 + lrow;
+      const i32x4 c16 = *reinterpret_cast<const i32x4*>(stage + ps * 64 + ((sseg ^ ((ps >> 2) & 3)) << 4));
       bstore16i(c16, ok ? pix * a.C + chunk * 64 + sseg * 16 : BUF_BIG, r_c);
     }
   }
