@@ -282,7 +282,7 @@ bool conv_pw_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int6
   if (R != 1 || S != 1 || stride != 1 || pad != 0 || dilation != 1 || dual || out || ep.residual || !ep.codes) return false;
   if (!epi_plain(ep)) return false;                             // (other quantisers: the tiled kernel)
   if (!(C == 64 || C == 128 || C == 192 || C == 512)) return false;
-  if (!(K == 192 || K % 128 == 0) || K > 1024) return false;
+  if (!(K == 64 || K == 192 || K % 128 == 0) || K > 1024) return false;
   if (!aligned16(ep.codes)) return false;
   const int64_t M = N * H * W;
   if (M < 4096) return false;                                   // (the weights are loaded once per workgroup: a few blocks per wave at least)
@@ -313,7 +313,7 @@ static int pw_go(const PwArgs& a0, const ConvEpi& ep, hipStream_t st) {
   if (ngroups < 8) ngroups = 8;
   const int maxg = ((a.nblk + NW - 1) / NW + 7) & ~7;
   if (ngroups > maxg) ngroups = maxg;
-  constexpr int NTP = BN == 192 ? 3 : (C >= 512 ? 1 : 2);
+  constexpr int NTP = BN == 192 ? 3 : (C >= 512 ? 1 : 2);      // (64-wide slices: one pass of two blocks)
   auto kern = conv_pw_i8_kernel<C, BN, NTP, ASYM, NW, LAB>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -334,7 +334,7 @@ int conv_pw_launch(const int8_t* x, const int8_t* w, const float* bias, const in
   a.M = (int)(N * H * W); a.K = (int)K; a.shift = shift;
   a.nblk = (a.M + 31) / 32;
   const bool asym = ep.w_off != nullptr;
-  const int bn = K == 192 ? 192 : 128;
+  const int bn = K == 192 ? 192 : (K == 64 ? 64 : 128);
 #ifdef DLMCQ_LAB
 #define DLMCQ_PWL(CC, BB, L) \
   if (C == CC && bn == BB && lab == L && asym) return pw_go<CC, BB, true, L>(a, ep, st)
@@ -349,6 +349,7 @@ int conv_pw_launch(const int8_t* x, const int8_t* w, const float* bias, const in
   if (lab) return DLMCQ_EINVAL;
 #define DLMCQ_PW(CC, BB)                                         \
   if (C == CC && bn == BB) return asym ? pw_go<CC, BB, true>(a, ep, st) : pw_go<CC, BB, false>(a, ep, st)
+  DLMCQ_PW(64, 64);
   DLMCQ_PW(64, 128);
   DLMCQ_PW(64, 192);
   DLMCQ_PW(128, 128);

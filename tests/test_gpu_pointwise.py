@@ -18,6 +18,7 @@ CASES = [
     (6, 28, 28, 128, 256, False, True, True, False, 7.0),      # symmetric, two slices
     (12, 20, 20, 64, 192, True, False, True, False, 0.0),
     (9, 23, 23, 512, 128, False, True, True, False, 0.0),      # 4 761 pixels, one slice
+    (10, 24, 24, 64, 64, False, True, True, False, 0.0),       # ResNet-50's first reduction (64 -> 64): a 64-wide slice
 ]
 
 
