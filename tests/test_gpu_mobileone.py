@@ -132,6 +132,8 @@ def test_depthwise_kernel_shapes_and_forms():
     (2, 128, 56, 56, False, False, True, 3.0),      # the widest frame (57 positions per row), symmetric weights, a zero point
     (24, 512, 14, 14, True, True, False, 0.0),      # stage 3: eight chunks, signed codes (no re-centring of the fragments), no bias
     (5, 64, 33, 30, True, False, False, -7.0),
+    (1024, 192, 28, 28, False, True, True, 0.0),    # BASELINE configs[4] at its stated size: a stage-2 depthwise layer at batch 1024
+    (1024, 512, 14, 14, True, True, True, 0.0),     # ... and a stage-3 layer as the plan feeds it (re-centred codes)
 ])
 def test_depthwise_on_the_matrix_cores_is_the_vector_kernel_bit_for_bit(n, c, h, w, signed, asym, has_bias, zp):
     """csrc/conv_dwm_i8.hip (3x3 / stride 1 / padding 1, codes only, the plain quantiser, >= 4 096 pixels) against
