@@ -20,8 +20,8 @@
 //
 // Structure: the linear frame of conv3x3_i8.hip / conv_dwpw_i8.hip (image n as (H + 1) x (W + 1) positions with shared
 // zero-point borders: the nine taps are nine fixed shifts of one sequence).  A workgroup owns ONE 64-channel chunk - its four
-// waves one 16-channel segment each, weights and constants in registers for the whole launch - and walks tiles of 128 positions:
-// halo tiles by LDS-DMA (three buffers: the tile after next is requested before this tile's arithmetic; counted waits), two blocks'
+// waves one 16-channel segment each, weights and constants in registers for the whole launch - and walks tiles of 192 positions:
+// halo tiles by LDS-DMA (two buffers: the next tile is requested before this tile's arithmetic; counted waits), two blocks'
 // MFMA chains interleaved (five dependent instructions per block otherwise), fragments by ds_read_b128 at constant offsets,
 // codes through an LDS stage so that a position's 64 bytes leave together.  Same integers, same fp32 chain, same quantiser as
 // conv_dw3p2_i8_kernel: bit-identical (tests/test_gpu_mobileone.py).
@@ -45,16 +45,16 @@ struct DwmArgs {
   uint8_t* codes;            // [N][H][W][C]
 };
 
-constexpr int DWM_TP = 128;      // output positions per tile
+constexpr int DWM_TP = 192;      // output positions per tile (128: +2.6 % time - the requests' and stores' fixed costs; 256 at two workgroups per CU: +6 %)
 
 // XS: the input codes are signed bytes (int8 codes, or an unsigned quantiser's codes handed over as `code - 128`): no re-centring
 // of the fragments (4 vector instructions per MFMA otherwise)
 template <int HPW, bool XS>
 __global__ __launch_bounds__(256, 3) void conv_dwm_i8_kernel(DwmArgs a, ConvEpi ep) {
   constexpr int HALO = HPW * 4 * 1024;                 // bytes of one halo buffer (16 positions x 64 B per piece)
-  constexpr int NHB = HPW <= 3 ? 3 : 2;                // halo buffers: the halo of tile t + NHB - 1 is requested while tile t is worked on
+  constexpr int NHB = 2;                               // halo buffers: the halo of tile t + NHB - 1 is requested while tile t is worked on (three: no faster)
   __shared__ __attribute__((aligned(1024))) int8_t lds[NHB * HALO + DWM_TP * 64];
-  int8_t* const stage = lds + NHB * HALO;              // [128 positions][64 B]: this chunk's codes
+  int8_t* const stage = lds + NHB * HALO;              // [DWM_TP positions][64 B]: this chunk's codes
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
   const uint32_t b = blockIdx.x;
@@ -230,7 +230,7 @@ bool conv_dwm_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t R, int
                       const float* out, const void* x) {
   if (R != 3 || S != 3 || stride != 1 || pad != 1 || out || !epi_plain(ep)) return false;
   if (C < 64 || (C & 63) || !aligned16(x) || !aligned16(ep.codes)) return false;
-  if ((DWM_TP + 2 * (W + 1) + 2 + 15) / 16 > 16 || W < 14) return false;        // (a piece of 16 positions wraps at most one frame row)
+  if ((DWM_TP + 2 * (W + 1) + 2 + 15) / 16 > 20 || W < 14) return false;        // (a piece of 16 positions wraps at most one frame row)
   if (N * (H + 1) * (W + 1) + 4096 >= (1ll << 31) || N * H * W * C >= (int64_t)BUF_BIG) return false;     // 32-bit positions and buffer offsets
   return N * H * W >= 4096;                                     // (weights and constants are set up once per workgroup)
 }
@@ -269,8 +269,8 @@ int conv_dwm_launch(const int8_t* x, const int8_t* w, const float* bias, const f
     if (x_signed) hipLaunchKernelGGL((conv_dwm_i8_kernel<HP_, true>), grid, block, 0, st, a, ep);  \
     else hipLaunchKernelGGL((conv_dwm_i8_kernel<HP_, false>), grid, block, 0, st, a, ep);          \
   } while (0)
-  if (hpw <= 3) DLMCQ_DWM_GO(3);
-  else DLMCQ_DWM_GO(4);
+  if (hpw <= 4) DLMCQ_DWM_GO(4);
+  else DLMCQ_DWM_GO(5);
 #undef DLMCQ_DWM_GO
   return launch_status();
 }
