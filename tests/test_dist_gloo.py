@@ -45,8 +45,8 @@ def _worker(rank, world, port, q):
         gmx, gnmn = allreduce_minmax(mx.clone(), nmn.clone())
         gab, none = allreduce_minmax(ab.clone())
         assert none is None
-        out[ch_axis] = (gmx, gnmn, gab)
-    q.put((rank, out))
+        out[ch_axis] = (gmx.tolist(), gnmn.tolist(), gab.tolist())     # (plain lists: a tensor in the queue travels as a shared-memory
+    q.put((rank, out))                                                  #  file that is gone if this process exits before the parent reads it)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -70,10 +70,10 @@ def test_observer_allreduce_world2():
     for ch_axis in (None, 1):
         wmx, wnmn, wab = _local_minmax(full, ch_axis)
         for rank in range(world):
-            gmx, gnmn, gab = results[rank][ch_axis]
+            gmx, gnmn, gab = (torch.tensor(v) for v in results[rank][ch_axis])
             assert torch.equal(gmx, wmx) and torch.equal(gnmn, wnmn) and torch.equal(gab, wab)
         # and the scale/offset every rank derives == the single-process observer over the whole batch
-        gmx, gnmn, gab = results[0][ch_axis]
+        gmx, gnmn, gab = (torch.tensor(v) for v in results[0][ch_axis])
         if ch_axis is None:
             s_u, o_u = O.minmax_tensor(full, 8, False)
             s_s, _ = O.minmax_tensor(full, 8, True)
