@@ -204,7 +204,7 @@ def families(records):
 
 FAMILY_KERNEL = {"conv_chain": "conv_chain_i8_kernel", "conv_i8": "conv_i8_mfma_kernel", "conv3x3_halo": "conv3x3_halo_i8_kernel",
                  "conv_dw": "conv_dw3_i8_kernel / conv_dw3p2_i8_kernel", "conv_dwm": "conv_dwm_i8_kernel", "conv_stem": "conv_stem_i8_kernel / conv_stem_pool7_i8_kernel",
-                 "conv_dwpw": "conv_dwpw_i8_kernel", "conv_pw": "conv_pw_i8_kernel", "fq_image": "quantize_pad_nhwc4_kernel"}
+                 "conv_dwpw": "conv_dwpw_i8_kernel", "conv_pw": "conv_pw_i8_kernel", "conv_pwr": "conv_pwr_i8_kernel", "fq_image": "quantize_pad_nhwc4_kernel"}
 
 
 def family_roofline(tag, f):

@@ -460,7 +460,12 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
     pw = (not linear and (R, S) == (1, 1) and stride == 1 and padding == 0 and dilation == 1 and not want_out and emit is not None
           and residual is None and c in (64, 128, 192, 512) and (K in (64, 192) or K % 128 == 0) and K <= 1024 and n * h * w_ >= 4096
           and n * h * w_ * max(c, K) < 0x7fff0000 and emit.zero_point is None and (emit.lo, emit.hi) == (0, 255))
-    tag = "conv3x3_halo" if halo else ("conv_pw" if pw else "conv_i8")
+    # ... and conv_pwr_applies (csrc/conv_pwr_i8.hip: 1x1 block ends with an fp32 shortcut, ReLU and the consumer's plain codes)
+    pwr = (not linear and (R, S) == (1, 1) and stride == 1 and padding == 0 and dilation == 1 and residual is not None
+           and relu and w_offset is None and c in (256, 512) and K % 128 == 0 and K <= 4096 and n * h * w_ >= 4096 and (n * h * w_) % 32 == 0
+           and n * h * w_ * K * 4 < 0x7fff0000
+           and (want_out if emit is None else (emit.zero_point is None and (emit.lo, emit.hi) == (0, 255))))
+    tag = "conv3x3_halo" if halo else ("conv_pw" if pw else ("conv_pwr" if pwr else "conv_i8"))
     if fused:
         out_codes = q_scale = q_zp = None
         lo = hi = form = 0

@@ -137,3 +137,116 @@ def test_pointwise_kernel_leaves_the_rest_to_the_tiled_kernel():
         K.conv2d_i8(codes[:, :128].contiguous(memory_format=torch.channels_last), wq[..., :128].contiguous(), wsum, None, one, None, s_w,
                     relu=True, emit=emit, want_out=True)                                                   # fp32 output wanted
     assert _tagged(K, both)[1] == ["conv_i8", "conv_i8"]
+
+
+# csrc/conv_pwr_i8.hip: (N, H, W, C, K, fp32 output stored as well, signed input codes, input zero point, codes emitted as `code - 128`)
+RES_CASES = [
+    (32, 14, 14, 256, 1024, False, True, 0.0, False),     # ResNet-50 stage 3's last block end (codes only: the next block's shortcut is a convolution)
+    (32, 14, 14, 256, 1024, True, False, 0.0, False),
+    (128, 7, 7, 512, 2048, True, True, 0.0, True),        # stage 4 (fp32 block output + codes), codes handed on re-centred
+    (96, 7, 7, 512, 2048, False, False, 5.0, False),      # 4 704 pixels = 147 blocks, a zero point
+    (24, 14, 14, 256, 128, True, True, 0.0, False),       # one slice; 147 blocks: fewer than the waves of its workgroups
+    (512, 14, 14, 256, 1024, False, True, 0.0, False),    # BASELINE configs[2] at its stated size: the two shapes of the ResNet-50 plan at batch 512
+    (512, 7, 7, 512, 2048, True, True, 0.0, False),
+]
+
+
+@pytest.mark.parametrize("case", RES_CASES, ids=lambda c: "x".join(str(int(v)) if not isinstance(v, bool) else "ft"[v] for v in c))
+def test_residual_block_end_kernel_is_the_tiled_kernel_bit_for_bit(case):
+    """The 1x1 block end with an fp32 shortcut (+ fp32 output) + ReLU + plain codes on the weight-resident kernel: the same bytes -
+    codes AND fp32 values - as the tiled kernel's residual epilogue, and a float64 reference within one code."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    n, h, w, c, k, want_out, signed, zp, shifted = case
+    g = torch.Generator(device=DEV).manual_seed(n * 1000 + c + k + int(want_out))
+    if signed:
+        codes = torch.randint(-128, 128, (n, c, h, w), generator=g, device=DEV, dtype=torch.int8)
+    else:
+        codes = torch.randint(0, 256, (n, c, h, w), generator=g, device=DEV, dtype=torch.uint8)
+    codes = codes.contiguous(memory_format=torch.channels_last)
+    wq = torch.randint(-127, 128, (k, 1, 1, c), generator=g, device=DEV, dtype=torch.int8)
+    wsum = wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
+    s_w = (torch.rand(k, generator=g, device=DEV) * 0.0004 + 0.00005).contiguous()
+    bias = torch.randn(k, generator=g, device=DEV).contiguous()
+    short = (torch.randn((n, k, h, w), generator=g, device=DEV) * 2.0).contiguous(memory_format=torch.channels_last)
+    short[0, :8, 0, 0] = torch.tensor([float("nan"), float("inf"), -float("inf"), 0.0, -0.0, 1e30, -1e30, 0.0215], device=DEV)
+    s_in = torch.full((1,), 0.021, device=DEV)
+    in_zp = torch.full((1,), zp, device=DEV)
+    q_scale = torch.full((1,), 0.043, device=DEV)
+    emit = K.EmitCodes(q_scale, None, 0, 255, N.FORM_ZEROPOINT, shift128=shifted)
+
+    def run(cd, sc):
+        return K.conv2d_i8(cd, wq, wsum, bias, s_in, in_zp, s_w, residual=sc, relu=True, emit=emit, want_out=want_out)
+    (out, got), tags = _tagged(K, lambda: run(codes, short))
+    assert tags == ["conv_pwr"], tags
+    torch.cuda.synchronize()
+    nsub = max(1, 4095 // (h * w))
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    for sl in (slice(0, nsub), slice(n - nsub, n)):        # the tiled kernel on the first and on the last images (fewer than 4 096 pixels)
+        (osub, csub), tags = _tagged(K, lambda: run(cl(codes[sl]), cl(short[sl])))
+        assert tags == ["conv_i8"], tags
+        assert torch.equal(got[sl], csub), f"{int((got[sl] != csub).sum())} codes differ from the tiled kernel"
+        if want_out:
+            assert torch.equal(out[sl].view(torch.int32), osub.view(torch.int32)), "fp32 block output differs from the tiled kernel (bitwise)"
+    m = n * h * w
+    if m <= 8192:
+        x = (codes.permute(0, 2, 3, 1).reshape(m, c).double() - zp) * 0.021
+        y = x @ (wq.reshape(k, c).double() * s_w.double()[:, None]).t() + bias.double() + short.permute(0, 2, 3, 1).reshape(m, k).double()
+        y = torch.relu(y)
+        want = torch.clamp(torch.round(y / 0.043), 0, 255)
+        ok = torch.isfinite(y)
+        gq = got.permute(0, 2, 3, 1).reshape(m, k).double() + (128 if shifted else 0)
+        diff = (gq - want).abs()[ok]
+        assert float(diff.max()) <= 1.0 and float((diff > 0).double().mean()) < 1e-3, (float(diff.max()), float((diff > 0).double().mean()))
+        if want_out:
+            o = out.permute(0, 2, 3, 1).reshape(m, k).double()
+            assert float((o - y).abs()[ok].max()) < 1e-3
+
+
+def test_residual_block_end_kernel_declines_what_it_was_not_built_for():
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator(device=DEV).manual_seed(6)
+    codes = torch.randint(0, 256, (23, 256, 14, 14), generator=g, device=DEV, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)   # 4 508 pixels: not a multiple of 32
+    wq = torch.randint(-127, 128, (128, 1, 1, 256), generator=g, device=DEV, dtype=torch.int8)
+    wsum = wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
+    s_w = torch.full((128,), 0.0002, device=DEV)
+    one = torch.full((1,), 0.02, device=DEV)
+    short = torch.randn((23, 128, 14, 14), generator=g, device=DEV).contiguous(memory_format=torch.channels_last)
+    emit = K.EmitCodes(torch.full((1,), 0.05, device=DEV), None, 0, 255, N.FORM_ZEROPOINT)
+    emit_z = K.EmitCodes(torch.full((1,), 0.05, device=DEV), torch.full((1,), 3.0, device=DEV), 0, 255, N.FORM_ZEROPOINT)
+
+    def three():
+        K.conv2d_i8(codes, wq, wsum, None, one, None, s_w, residual=short, relu=True, emit=emit, want_out=False)          # ragged block count
+        K.conv2d_i8(codes[:22].contiguous(memory_format=torch.channels_last), wq, wsum, None, one, None, s_w,
+                    residual=short[:22].contiguous(memory_format=torch.channels_last), relu=True, emit=emit_z, want_out=False)   # a zero point
+        K.conv2d_i8(codes[:22].contiguous(memory_format=torch.channels_last), wq, wsum, None, one, None, s_w,
+                    residual=short[:22].contiguous(memory_format=torch.channels_last), relu=False, emit=emit, want_out=False)    # no ReLU
+    assert _tagged(K, three)[1] == ["conv_i8"] * 3
+
+
+@pytest.mark.parametrize("shape", [(128, 7, 7, 512, 2048), (32, 14, 14, 256, 384), (512, 7, 7, 512, 2048)], ids=str)
+def test_residual_block_end_kernel_without_codes(shape):
+    """A network's last block (fp32 output alone: nothing quantises the pooled features' producer): same fp32 bits as the tiled kernel."""
+    from dlmc.quantization.scalar import kernels as K
+    n, h, w, c, k = shape
+    g = torch.Generator(device=DEV).manual_seed(n + c + k)
+    codes = torch.randint(-128, 128, (n, c, h, w), generator=g, device=DEV, dtype=torch.int8).contiguous(memory_format=torch.channels_last)
+    wq = torch.randint(-127, 128, (k, 1, 1, c), generator=g, device=DEV, dtype=torch.int8)
+    wsum = wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
+    s_w = (torch.rand(k, generator=g, device=DEV) * 0.0004 + 0.00005).contiguous()
+    bias = torch.randn(k, generator=g, device=DEV).contiguous()
+    short = (torch.randn((n, k, h, w), generator=g, device=DEV) * 2.0).contiguous(memory_format=torch.channels_last)
+    short[0, :4, 0, 0] = torch.tensor([float("nan"), float("inf"), -float("inf"), -0.0], device=DEV)
+    s_in = torch.full((1,), 0.021, device=DEV)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+
+    def run(cd, sc):
+        return K.conv2d_i8(cd, wq, wsum, bias, s_in, None, s_w, residual=sc, relu=True)
+    out, tags = _tagged(K, lambda: run(codes, short))
+    assert tags == ["conv_pwr"], tags
+    nsub = max(1, 4095 // (h * w))
+    for sl in (slice(0, nsub), slice(n - nsub, n)):
+        osub, tags = _tagged(K, lambda: run(cl(codes[sl]), cl(short[sl])))
+        assert tags == ["conv_i8"], tags
+        assert torch.equal(out[sl].view(torch.int32), osub.view(torch.int32))
