@@ -693,8 +693,8 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   if (!forced && ep.w_off && plan.bn == 64 && K % 192 == 0 && plan.swap && ep.codes && !out && !ep.residual && aligned16(ep.codes)) plan.bn = 192;
   if (plan.halo && conv_pw_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
     return conv_pw_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, shift, ep, st);
-  if (plan.halo && conv_pwr_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
-    return conv_pwr_launch(xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, shift, ep, st);
+  if (plan.halo && conv_pwr_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2))
+    return conv_pwr_launch(xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st, seg2);
   if (plan.halo && conv3x3_halo_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
     return conv3x3_halo_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st);
   // 256-wide tiles exist for the swapped codes-only layers only (one third fewer operand bytes per MAC, two workgroups per CU)

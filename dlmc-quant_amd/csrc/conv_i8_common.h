@@ -107,10 +107,10 @@ int conv_pw_launch(const int8_t* x, const int8_t* w, const float* bias, const in
 
 // conv_pwr_i8.hip: 1 x 1 block ends with an fp32 shortcut (+ fp32 output) + ReLU + codes, the weights resident in LDS
 bool conv_pwr_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
-                      int32_t dilation, const ConvEpi& ep, const float* out, bool dual);
+                      int32_t dilation, const ConvEpi& ep, const float* out, const ConvSeg2* seg2);
 int conv_pwr_launch(const int8_t* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum, const float* in_scale,
-                    const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int shift,
-                    const ConvEpi& ep, hipStream_t st);
+                    const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int32_t stride,
+                    int shift, const ConvEpi& ep, hipStream_t st, const ConvSeg2* seg2 = nullptr);
 
 // conv_dwm_i8.hip: depthwise 3 x 3 / stride 1 / padding 1 codes-to-codes layers on the matrix cores (diagonal weight fragments)
 bool conv_dwm_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t R, int64_t S, int32_t stride, int32_t pad, const ConvEpi& ep,

@@ -648,7 +648,13 @@ def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True):
     def touched(c, r, s_, stride):     # a strided 1x1 convolution reads only the pixels it samples
         return c.numel() // (stride * stride) if r == 1 and s_ == 1 else c.numel()
     nbytes = touched(ca, R, S, st) + touched(cb, R2, S2, st2) + a["wq"].numel() + b["wq"].numel() + oe * (4 * want_out + (emit is not None))
-    PROFILE.launch("conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_dual(
+    # which kernel of the library takes the launch (conv_pwr_applies, csrc/conv_pwr_i8.hip: the dual form with both weight slices in LDS)
+    pwr = (relu and want_out and emit is not None and emit.zero_point is None and (emit.lo, emit.hi) == (0, 255)
+           and (R, S, pd, dl, R2, S2, pd2, dl2) == (1, 1, 0, 1, 1, 1, 0, 1) and K_ % 128 == 0 and K_ <= 4096
+           and ((st == 1 and ch == 256 and ch2 == 512) or (st2 == 1 and ch2 == 256 and ch == 512))
+           and n * P * Q >= 4096 and (n * P * Q) % 32 == 0 and n * P * Q * K_ * 4 < 0x7fff0000
+           and (cb.numel() if ch2 == 512 else ca.numel()) < 0x7fff0000)
+    PROFILE.launch("conv_pwr" if pwr else "conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_dual(
         N.ptr(ca), N.ptr(a["wq"]), N.ptr(out), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa),
         n, h, w_, ch, K_, R, S, st, pd, dl, uns,
         N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2, ch2, R2, S2, st2, pd2, dl2,

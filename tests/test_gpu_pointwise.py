@@ -250,3 +250,59 @@ def test_residual_block_end_kernel_without_codes(shape):
         osub, tags = _tagged(K, lambda: run(cl(codes[sl]), cl(short[sl])))
         assert tags == ["conv_i8"], tags
         assert torch.equal(out[sl].view(torch.int32), osub.view(torch.int32))
+
+
+# the dual form: (N, output H = W, stride of the 512-channel pair, K, which pair is the call's first: "dense" (256 channels, row by row) or "sampled")
+DUAL_CASES = [
+    (32, 14, 2, 1024, "sampled"),      # ResNet-50 stage 3's first block as the plan calls it (shortcut convolution first)
+    (32, 14, 2, 1024, "dense"),
+    (24, 14, 1, 256, "dense"),         # an unstrided shortcut convolution, two slices
+    (512, 14, 2, 1024, "sampled"),     # BASELINE configs[2] at its stated size
+]
+
+
+@pytest.mark.parametrize("case", DUAL_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_dual_block_end_kernel_is_the_tiled_kernel_bit_for_bit(case):
+    """conv1x1(256 ch) + conv1x1(512 ch, strided) + ReLU -> fp32 + plain codes with both weight slices resident in LDS: the same
+    fp32 bits and codes as the tiled kernel's DUAL instantiation (sub-batches below 4 096 pixels), float64 reference within one code."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    n, hw, st, k, first = case
+    g = torch.Generator(device=DEV).manual_seed(n + hw + st + k)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    xd = cl(torch.randint(-128, 128, (n, 256, hw, hw), generator=g, device=DEV, dtype=torch.int8))
+    xs = cl(torch.randint(0, 256, (n, 512, hw * st, hw * st), generator=g, device=DEV, dtype=torch.uint8))
+
+    def operand(x, c, stride, seed):
+        gg = torch.Generator(device=DEV).manual_seed(seed)
+        wq = torch.randint(-127, 128, (k, 1, 1, c), generator=gg, device=DEV, dtype=torch.int8)
+        return dict(codes=x, wq=wq, wsum=wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous(),
+                    bias=torch.randn(k, generator=gg, device=DEV), in_scale=torch.full((1,), 0.017 + 0.001 * seed, device=DEV),
+                    in_zp=torch.full((1,), float(seed), device=DEV) if x.dtype == torch.uint8 else None,
+                    w_scale=(torch.rand(k, generator=gg, device=DEV) * 0.0004 + 0.00005).contiguous(), stride=stride)
+    dense, sampled = operand(xd, 256, 1, 3), operand(xs, 512, st, 5)
+    emit = K.EmitCodes(torch.full((1,), 0.043, device=DEV), None, 0, 255, N.FORM_ZEROPOINT)
+
+    def run(sl):
+        d, s_ = dict(dense, codes=cl(xd[sl])), dict(sampled, codes=cl(xs[sl]))
+        a, b = (d, s_) if first == "dense" else (s_, d)
+        return K.conv2d_i8_dual(a, b, relu=True, emit=emit, want_out=True)
+    (out, got), tags = _tagged(K, lambda: run(slice(0, n)))
+    assert tags == ["conv_pwr"], tags
+    nsub = max(1, 4095 // (hw * hw))
+    for sl in (slice(0, nsub), slice(n - nsub, n)):
+        (osub, csub), tags = _tagged(K, lambda: run(sl))
+        assert tags == ["conv_i8"], tags
+        assert torch.equal(got[sl], csub), f"{int((got[sl] != csub).sum())} codes differ from the tiled kernel"
+        assert torch.equal(out[sl].view(torch.int32), osub.view(torch.int32)), "fp32 output differs from the tiled kernel (bitwise)"
+    m = n * hw * hw
+    if m <= 8192:
+        def real(t, x):
+            zp = 0.0 if t["in_zp"] is None else float(t["in_zp"])
+            xx = x[:, :, ::t["stride"], ::t["stride"]].permute(0, 2, 3, 1).reshape(m, -1).double()
+            return ((xx - zp) * float(t["in_scale"])) @ (t["wq"].reshape(k, -1).double() * t["w_scale"].double()[:, None]).t() + t["bias"].double()
+        y = torch.relu(real(dense, xd) + real(sampled, xs))
+        want = torch.clamp(torch.round(y / 0.043), 0, 255)
+        diff = (got.permute(0, 2, 3, 1).reshape(m, k).double() - want).abs()
+        assert float(diff.max()) <= 1.0 and float((diff > 0).double().mean()) < 1e-3, (float(diff.max()), float((diff > 0).double().mean()))
+        assert float((out.permute(0, 2, 3, 1).reshape(m, k).double() - y).abs().max()) < 1e-3

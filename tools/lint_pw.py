@@ -123,7 +123,7 @@ def queue_check(name, body, loads_per_block):
                 break
             if re.match(r"(buffer|global)_(load|store|atomic)", line):
                 ml = re.match(r"buffer_load_dwordx4 v\[(\d+):(\d+)\]", line)
-                q = (q + ((j, (int(ml.group(1)), int(ml.group(2))) if ml else None),))[-63:]
+                q = (q + (((j, (int(ml.group(1)), int(ml.group(2)))) if ml else (None, None)),))[-63:]     # (stores and LDS-DMA: anonymous, so that the prologue's loops converge)
                 if ml:
                     inloop.add(j)
             mb = re.match(r"(s_branch|s_cbranch_\w+)\s+(\.LBB\d+_\d+)", line)
