@@ -65,7 +65,9 @@ constexpr int halo_cs(bool s2, int t) { return !s2 ? t % 3 : (halo_tap(true, t) 
 // WPE = waves per SIMD the registers are budgeted for.  XS = the activation codes are uint8 and every pixel fragment is re-centred
 // (^ 0x80) on its way to the matrix cores; producers that emit `code - 128` (DLMCQ_EMIT_SHIFT128) spare this kernel 16 of its ~45
 // vector instructions per K step.
-template <int BN, int TM, int NW, int WC, int HPW, int NHB, int WPE, bool XS, int LAB = 0, bool S2 = false, int HPA = HPW * NW>
+// PLAIN (the launcher has checked epi_plain): the consumer's quantiser is the plain unsigned-byte one - the epilogue on channel pairs with
+// EpiQuant::code4n_plain (conv_epilogue.h; 6.75 instead of ~9 vector instructions per element), the same bytes.
+template <int BN, int TM, int NW, int WC, int HPW, int NHB, int WPE, bool XS, int LAB = 0, bool S2 = false, int HPA = HPW * NW, bool PLAIN = false>
 __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, const float* __restrict__ bias, const int32_t* __restrict__ wsum,
     const float* __restrict__ s_in, const float* __restrict__ zp_in, const float* __restrict__ s_w, HaloGeom g, int shift, ConvEpi ep,
@@ -377,15 +379,22 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
         const f32x4 mu = *reinterpret_cast<const f32x4*>(par + (cb + 4 * q) * 4);
         const i32x4 co = *reinterpret_cast<const i32x4*>(par + (BN + cb + 4 * q) * 4);
         const f32x4 bs = bias ? *reinterpret_cast<const f32x4*>(par + (2 * BN + cb + 4 * q) * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        y[q] = f32x4{dequant1(acc[jc][jp][4 * q] + co.x, mu.x, bs.x), dequant1(acc[jc][jp][4 * q + 1] + co.y, mu.y, bs.y),
-                     dequant1(acc[jc][jp][4 * q + 2] + co.z, mu.z, bs.z), dequant1(acc[jc][jp][4 * q + 3] + co.w, mu.w, bs.w)};
+        if constexpr (PLAIN) {
+          const f32x2 ya = pk_fma(f32x2{(float)(acc[jc][jp][4 * q] + co.x), (float)(acc[jc][jp][4 * q + 1] + co.y)}, f32x2{mu.x, mu.y}, f32x2{bs.x, bs.y});
+          const f32x2 yb = pk_fma(f32x2{(float)(acc[jc][jp][4 * q + 2] + co.z), (float)(acc[jc][jp][4 * q + 3] + co.w)}, f32x2{mu.z, mu.w}, f32x2{bs.z, bs.w});
+          y[q] = f32x4{ya.x, ya.y, yb.x, yb.y};
+        } else {
+          y[q] = f32x4{dequant1(acc[jc][jp][4 * q] + co.x, mu.x, bs.x), dequant1(acc[jc][jp][4 * q + 1] + co.y, mu.y, bs.y),
+                       dequant1(acc[jc][jp][4 * q + 2] + co.z, mu.z, bs.z), dequant1(acc[jc][jp][4 * q + 3] + co.w, mu.w, bs.w)};
+        }
       }
       uint32_t wq[4];
       bool uq[4];
       if (LAB == 7) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) wq[q] = __builtin_bit_cast(uint32_t, y[q].x + y[q].y + y[q].z + y[q].w);
-      } else eq.code4n(y, wq, uq);
+      } else if constexpr (PLAIN) eq.code4n_plain(y, wq);
+      else eq.code4n(y, wq, uq);
       const i32x4 c16 = i32x4{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
       if (LAB == 8) {
         if (ok8) __builtin_nontemporal_store(c16, reinterpret_cast<i32x4*>(dst8 + cb));
@@ -450,6 +459,7 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
   constexpr int TM = 256;
   const int bn = K % 128 == 0 ? 128 : 64;
   const bool s2 = stride == 2;
+  const bool plain = epi_plain(ep);
   HaloGeom g;
   g.N = (int)N; g.Hin = (int)H; g.Win = (int)W; g.H = (int)(H / stride); g.W = (int)(W / stride); g.C = (int)C; g.K = (int)K;
   g.Wp = g.W + 1;
@@ -507,10 +517,12 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
     // stride 2: three phase-tile buffers of 18 pieces (Wp <= 30: two workgroups per CU at 128 channels) or 20 (Wp <= 62)
     if (g.hp > 20) return DLMCQ_EINVAL;
     const bool big = g.hp > 18;
-#define DLMCQ_HALO_S2(BN_, HPA_, WPE_)                                                                                             \
-  do {                                                                                                                            \
-    if (shift) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, 5, 3, WPE_, true, 0, true, HPA_>), DLMCQ_HALO_ARGS(4));   \
-    else hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, 5, 3, WPE_, false, 0, true, HPA_>), DLMCQ_HALO_ARGS(4));        \
+#define DLMCQ_HALO_S2(BN_, HPA_, WPE_)                                                                                                         \
+  do {                                                                                                                                        \
+    if (shift && plain) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, 5, 3, WPE_, true, 0, true, HPA_, true>), DLMCQ_HALO_ARGS(4));  \
+    else if (shift) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, 5, 3, WPE_, true, 0, true, HPA_>), DLMCQ_HALO_ARGS(4));            \
+    else if (plain) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, 5, 3, WPE_, false, 0, true, HPA_, true>), DLMCQ_HALO_ARGS(4));     \
+    else hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, 5, 3, WPE_, false, 0, true, HPA_>), DLMCQ_HALO_ARGS(4));                      \
   } while (0)
     if (bn == 128) {
       if (!big) DLMCQ_HALO_S2(128, 18, 2);
@@ -525,20 +537,22 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
   if (g.hp > 32) return DLMCQ_EINVAL;
   const bool wide = g.hp > 24;        // images wider than 57 pixels: 8 halo pieces per wave, one workgroup per CU
 #undef DLMCQ_HALO_GO
-#define DLMCQ_HALO_GO(NW, ...)                                                                            \
-  do {                                                                                                   \
-    if (shift) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<__VA_ARGS__, true>), DLMCQ_HALO_ARGS(NW));    \
-    else hipLaunchKernelGGL((conv3x3_halo_i8_kernel<__VA_ARGS__, false>), DLMCQ_HALO_ARGS(NW));         \
+#define DLMCQ_HALO_GO(BN_, HPW_, NHB_, WPE_)                                                                                                              \
+  do {                                                                                                                                                   \
+    if (shift && plain) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, HPW_, NHB_, WPE_, true, 0, false, 4 * HPW_, true>), DLMCQ_HALO_ARGS(4));  \
+    else if (shift) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, HPW_, NHB_, WPE_, true>), DLMCQ_HALO_ARGS(4));                                \
+    else if (plain) hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, HPW_, NHB_, WPE_, false, 0, false, 4 * HPW_, true>), DLMCQ_HALO_ARGS(4));     \
+    else hipLaunchKernelGGL((conv3x3_halo_i8_kernel<BN_, TM, 4, 1, HPW_, NHB_, WPE_, false>), DLMCQ_HALO_ARGS(4));                                          \
   } while (0)
   if (bn == 128) {
-    if (!wide) DLMCQ_HALO_GO(4, 128, TM, 4, 1, 6, 2, 2);
-    else DLMCQ_HALO_GO(4, 128, TM, 4, 1, 8, 2, 1);
+    if (!wide) DLMCQ_HALO_GO(128, 6, 2, 2);
+    else DLMCQ_HALO_GO(128, 8, 2, 1);
   } else if (C == 64) {
-    if (!wide) DLMCQ_HALO_GO(4, 64, TM, 4, 1, 6, 1, 4);
-    else DLMCQ_HALO_GO(4, 64, TM, 4, 1, 8, 1, 3);
+    if (!wide) DLMCQ_HALO_GO(64, 6, 1, 4);
+    else DLMCQ_HALO_GO(64, 8, 1, 3);
   } else {
-    if (!wide) DLMCQ_HALO_GO(4, 64, TM, 4, 1, 6, 2, 2);
-    else DLMCQ_HALO_GO(4, 64, TM, 4, 1, 8, 2, 2);
+    if (!wide) DLMCQ_HALO_GO(64, 6, 2, 2);
+    else DLMCQ_HALO_GO(64, 8, 2, 2);
   }
 #undef DLMCQ_HALO_GO
 #undef DLMCQ_HALO_ARGS

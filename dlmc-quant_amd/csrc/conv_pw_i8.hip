@@ -36,7 +36,7 @@ struct PwArgs {
 };
 
 // waves per SIMD the kernel is compiled for (registers: fragments C / 8 + accumulators of one pass + ~70 for the epilogue)
-constexpr int PW_WPS(int c, int bn) { return c >= 512 ? 3 : 4; }
+constexpr int PW_WPS(int c, int bn) { return c >= 1024 ? 1 : (c >= 512 ? 3 : 4); }
 
 // LAB (lab library only, what-bounds-the-block experiments: results are garbage): 1 = clock stamps of one wave, 2 = no activation
 // loads, 4 = no MFMAs, 6 = epilogue without its arithmetic, 7 = no epilogue and no stores, 8 = no stores, 9 = non-temporal stores
@@ -281,7 +281,7 @@ bool conv_pw_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int6
                      int32_t dilation, const ConvEpi& ep, const float* out, bool dual) {
   if (R != 1 || S != 1 || stride != 1 || pad != 0 || dilation != 1 || dual || out || ep.residual || !ep.codes) return false;
   if (!epi_plain(ep)) return false;                             // (other quantisers: the tiled kernel)
-  if (!(C == 64 || C == 128 || C == 192 || C == 512)) return false;
+  if (!(C == 64 || C == 128 || C == 192 || C == 512 || C == 1024)) return false;
   if (!(K == 64 || K == 192 || K % 128 == 0) || K > 1024) return false;
   if (!aligned16(ep.codes)) return false;
   const int64_t M = N * H * W;
@@ -295,9 +295,10 @@ static int pw_go(const PwArgs& a0, const ConvEpi& ep, hipStream_t st) {
   constexpr int WPS = PW_WPS(C, BN);
   constexpr int LDS1 = C * BN + 4 * BN * 4, STG = 4 * 32 * (BN + 16);   // weights + constants; one 4-wave workgroup's code stages
   // workgroups of 4 waves where WPS of them fit a CU's LDS, else ONE workgroup of 4 WPS waves per CU (one copy of the weights)
-  constexpr bool BIGWG = (LDS1 + STG) * WPS > 158 * 1024;
-  constexpr int NW = BIGWG ? 4 * WPS : 4;
-  constexpr int LDS = LDS1 + (NW / 4) * STG;
+  // (1 024 input channels: the 128 KB slice leaves room for six waves' stages)
+  constexpr bool BIGWG = C >= 1024 || (LDS1 + STG) * WPS > 158 * 1024;
+  constexpr int NW = C >= 1024 ? 6 : (BIGWG ? 4 * WPS : 4);
+  constexpr int LDS = LDS1 + NW * (STG / 4);
   static_assert(LDS <= 160 * 1024, "LDS");
   PwArgs a = a0;
   a.nslice = a.K / BN;
@@ -357,6 +358,7 @@ int conv_pw_launch(const int8_t* x, const int8_t* w, const float* bias, const in
   DLMCQ_PW(192, 128);
   DLMCQ_PW(192, 192);
   DLMCQ_PW(512, 128);
+  DLMCQ_PW(1024, 128);
 #undef DLMCQ_PW
   return DLMCQ_EINVAL;
 }

@@ -458,7 +458,7 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
             and (stride == 1 or Q + 1 <= 62) and not (stride == 2 and c == 64 and K != 64) and Q + 1 <= 120)
     # ... and conv_pw_applies (csrc/conv_pw_i8.hip: pointwise codes-to-codes layers, weights resident in LDS)
     pw = (not linear and (R, S) == (1, 1) and stride == 1 and padding == 0 and dilation == 1 and not want_out and emit is not None
-          and residual is None and c in (64, 128, 192, 512) and (K in (64, 192) or K % 128 == 0) and K <= 1024 and n * h * w_ >= 4096
+          and residual is None and c in (64, 128, 192, 512, 1024) and (K in (64, 192) or K % 128 == 0) and K <= 1024 and n * h * w_ >= 4096
           and n * h * w_ * max(c, K) < 0x7fff0000 and emit.zero_point is None and (emit.lo, emit.hi) == (0, 255))
     # ... and conv_pwr_applies (csrc/conv_pwr_i8.hip: 1x1 block ends with an fp32 shortcut, ReLU and the consumer's plain codes)
     pwr = (not linear and (R, S) == (1, 1) and stride == 1 and padding == 0 and dilation == 1 and residual is not None

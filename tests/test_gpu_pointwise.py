@@ -19,6 +19,8 @@ CASES = [
     (12, 20, 20, 64, 192, True, False, True, False, 0.0),
     (9, 23, 23, 512, 128, False, True, True, False, 0.0),      # 4 761 pixels, one slice
     (10, 24, 24, 64, 64, False, True, True, False, 0.0),       # ResNet-50's first reduction (64 -> 64): a 64-wide slice
+    (32, 14, 14, 1024, 256, False, True, True, True, 0.0),     # ResNet-50's stage-3 reductions (1 024 -> 256): a 128 KB weight slice, six waves per CU
+    (24, 14, 14, 1024, 512, False, True, True, False, 0.0),    # ... and the first layer of stage 4 (1 024 -> 512)
     (1024, 28, 28, 192, 192, True, True, True, False, 0.0),    # BASELINE configs[4] at its stated size: a stage-2 layer of MobileOne-S1 at batch 1024
     (1024, 14, 14, 512, 512, True, True, True, False, 0.0),    # ... and a stage-3 layer (154 / 103 M output elements: the 32-bit buffer offsets at size)
 ]
