@@ -252,7 +252,8 @@ def test_pointwise_kernel_listing_leaves_in_flight_fragments_alone():
     """tools/lint_pw.py on the cross-compiled listing: conv_pw_i8_kernel requests a block's activation fragments (asm buffer loads) in
     the middle of the previous block's epilogue and waits for them with a counted s_waitcnt at the top of its loop; nothing reachable
     in between (control-flow walk) may read, copy or overwrite those registers, the kernel uses no scratch, every asm store has its
-    wait states."""
+    wait states.  conv_pwr_i8_kernel (csrc/conv_pwr_i8.hip) keeps loads in flight ACROSS counted waits: the same script replays its
+    whole vector-memory queue along every path of the listing."""
     import shutil
     import subprocess
     import sys
@@ -261,3 +262,4 @@ def test_pointwise_kernel_listing_leaves_in_flight_fragments_alone():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "lint_pw.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "residual-block kernels checked, 0 problem(s)" in r.stdout, r.stdout
