@@ -343,7 +343,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of CPU work for the all-cores leg of cpu_baseline (half of it again on one thread)")
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
                     help="default model only: skip the short RepVGG-A1 b512 / MobileOne-S1 b1024 runs reported under `other_configs`")
-    ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each `other_configs` run (3 warm-up steps)")
+    ap.add_argument("--other-steps", type=int, default=50, help="timed steps of each `other_configs` run (10 warm-up steps)")
     args = ap.parse_args()
     args.int8 = args.conv == "int8"
     if args.batch is None:
