@@ -79,6 +79,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void conv3x3_halo_i8_kernel(
   if (LAB >= 9 && LAB <= 11 && blockIdx.x >= 256 && blockIdx.x < 512) {
     for (int i = 0; i < (LAB == 9 ? 4 : LAB == 10 ? 2 : 8); ++i) __builtin_amdgcn_s_sleep(127);
   }
+  // LAB 12 / 13 (timing only): four workgroups per CU (the 64-channel layers) - the first round's slot s (blockIdx / 256) starts s x 8 k / s x 4 k clocks late
+  if ((LAB == 12 || LAB == 13) && blockIdx.x < 1024) {
+    for (int i = 0; i < (int)((blockIdx.x >> 8) & 3u); ++i) {
+      if (LAB == 12) __builtin_amdgcn_s_sleep(127);
+      else __builtin_amdgcn_s_sleep(63);
+    }
+  }
   const unsigned long long t_start = STAMP ? __builtin_readcyclecounter() : 0ull;
   constexpr int NT = NW * 64;               // threads
   constexpr int NBUF = 3;
@@ -499,6 +506,7 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
       switch (v) {
 #define DLMCQ_HALO_LAB(V) case V: hipLaunchKernelGGL((conv3x3_halo_i8_kernel<64, TM, 4, 1, 6, 1, 4, true, V>), DLMCQ_HALO_ARGS(4)); break
         DLMCQ_HALO_LAB(1); DLMCQ_HALO_LAB(2); DLMCQ_HALO_LAB(3); DLMCQ_HALO_LAB(4); DLMCQ_HALO_LAB(6); DLMCQ_HALO_LAB(7); DLMCQ_HALO_LAB(8);
+        DLMCQ_HALO_LAB(12); DLMCQ_HALO_LAB(13);
 #undef DLMCQ_HALO_LAB
         default: return DLMCQ_EINVAL;
       }

@@ -19,7 +19,8 @@ from dlmc import _native as N  # noqa: E402
 
 CASES = {"c1": (64, 56, 64), "c1w": (64, 56, 128), "c2": (128, 28, 128), "c3": (256, 14, 256), "c4": (512, 7, 512)}   # C, H, K
 VARIANTS = {0: "product", 100: "8 waves of 64 x 64", 2: "no weight DMA", 3: "no halo DMA", 4: "no MFMA", 6: "no xor", 7: "no quantiser",
-            8: "codes not staged", 9: "2nd slot starts 1/2 tile late", 10: "2nd slot starts 1/4 tile late", 11: "2nd slot starts 1 tile late"}
+            8: "codes not staged", 9: "2nd slot starts 1/2 tile late", 10: "2nd slot starts 1/4 tile late", 11: "2nd slot starts 1 tile late",
+            12: "slot s of 4 starts s x 8 k clocks late", 13: "slot s of 4 starts s x 4 k clocks late"}
 
 
 def main():
@@ -66,7 +67,7 @@ def main():
                     bn, adir, 0, wps)
             if rc:
                 raise RuntimeError(f"{name} variant {v}: rc {rc}")
-        vs = ([-1] if args.generic else []) + [v for v in VARIANTS if (v < 100 and (v < 9 or k % 128 == 0)) or (v >= 100 and k % 128 == 0)]
+        vs = ([-1] if args.generic else []) + [v for v in VARIANTS if (v < 100 and (v < 9 or (k % 128 == 0 and v < 12) or (v >= 12 and c == 64 and k == 64))) or (v >= 100 and k % 128 == 0)]
         times = {v: [] for v in vs}
         for v in vs:
             run(v, 0)
