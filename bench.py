@@ -37,7 +37,8 @@ One JSON line on rank 0.  Besides the contract fields:
                        batch (8 B per fake-quantised activation / weight element) over the WHOLE step's time, against 8 TB/s.
                        An equivalent rate, not HBM traffic: the fused plan never moves most of those bytes.
   roofline_third_kernel   (round 4) the halo-tile 3x3 kernel and the generic kernel are separate families now (`conv3x3_halo` / `conv_i8`):
-                       second = the one with the larger share of the step, third = the other
+                       second = the one with the larger share of the step, third = the other; the weight-resident block-end kernel
+                       (`conv_pwr`) joins the ranking: the step's fourth family is `roofline_fourth_kernel`
   other_configs        (default model only) BASELINE configs[3]'s network (RepVGG-A1, 512 images per GPU) and configs[4] (MobileOne-S1
                        W4A8, 1024 per GPU) through the same pipeline, a short run each AFTER the headline region: value, ms_per_step,
                        steps and the roofline object of the family with the largest share of a profiled step
@@ -524,7 +525,7 @@ def main():
     chain = fam.get("conv_chain", empty)          # block end + next 1x1 in one kernel (csrc/conv_chain_i8.hip)
     conv_ops, chain_ops = conv.get("ops", 0), chain.get("ops", 0)     # 2 x MACs, recorded per launch (kernels.PROFILE)
     # `roofline` describes the kernel of this project with the largest share of the timed region
-    second_roof = third_roof = None
+    second_roof = third_roof = fourth_roof = None
     if max(conv["ms"], chain["ms"], halo["ms"]) > fq["ms"]:
         if args.fused:
             note = ("algorithmic bytes per launch = int8 input + int8 weights + what the epilogue moves (1 B/elem codes, "
@@ -540,9 +541,16 @@ def main():
                 ranked.append((halo["ms"], roof("conv3x3_halo", halo, "conv3x3_halo_i8_kernel (3x3 / pad 1 layers of stride 1 or 2 that emit only their "
                                                 "consumer's codes: linear-frame stencil over a halo tile staged once per 64-channel chunk)",
                                                 "algorithmic bytes per launch = int8 input + int8 weights + 1 B/elem codes out", ops=halo["ops"])))
+            pwr = fam.get("conv_pwr", empty)       # block ends outside the chains on the weight-resident kernel (csrc/conv_pwr_i8.hip)
+            if pwr["ms"] > 0:
+                ranked.append((pwr["ms"], roof("conv_pwr", pwr, "conv_pwr_i8_kernel (a block's last 1x1 convolution outside the chains: + fp32 shortcut or + a "
+                                               "second, sampled 1x1 convolution, ReLU, fp32 output and / or codes; weight slices resident in LDS)",
+                                               "algorithmic bytes per launch = int8 input(s) + int8 weights + 4 B/elem fp32 shortcut read + 4 B/elem fp32 output + "
+                                               "1 B/elem codes, as the layer has them", ops=pwr["ops"])))
             ranked = [r for ms, r in sorted(ranked, key=lambda t: -t[0]) if ms > 0]
             main_roof, second_roof = ranked[0], (ranked[1] if len(ranked) > 1 else None)
             third_roof = ranked[2] if len(ranked) > 2 else None
+            fourth_roof = ranked[3] if len(ranked) > 3 else None
         else:
             main_roof = roof("conv_i8", conv, "conv_i8_mfma_kernel (fused int8-dequant x GEMM conv/linear, fp32 NHWC out)",
                              "algorithmic bytes = int8 input + int8 weights + fp32 output per launch; the 1x1 layers are bound by "
@@ -558,7 +566,7 @@ def main():
         elif second_roof is None:
             second_roof = dw_roof
     if args.fused and max(conv["ms"], chain["ms"], halo["ms"]) > fq["ms"] and args.model == "resnet50" and args.batch == 512:
-        for r in (main_roof, second_roof, third_roof):
+        for r in (main_roof, second_roof, third_roof, fourth_roof):
             if r is None:
                 continue
             r["traffic"], src = pmc_traffic(r["kernel"].split(" ")[0])
@@ -619,6 +627,7 @@ def main():
         "roofline": main_roof,
         **({"roofline_second_kernel": second_roof} if second_roof else {}),
         **({"roofline_third_kernel": third_roof} if third_roof else {}),
+        **({"roofline_fourth_kernel": fourth_roof} if fourth_roof else {}),
         "roofline_fake_quant": fq_roof,
         "quant_path": {"images_per_s": round(args.batch * psteps / (qms * 1e-3), 1) if qms else None,
                        "GBps": round(qbytes / (qms * 1e-3) / 1e9, 1) if qms else None,

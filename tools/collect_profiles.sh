@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- pyt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/fetch.log" 2>&1 || echo "fetch pass failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/write.log" 2>&1 || echo "write pass failed"
 cd "$GRAFT_REPO_ROOT"
-python3 tools/pmc_summary.py --tail conv_chain_i8_kernel 11 --tail conv_i8_mfma_kernel 11 --tail conv3x3_halo_i8_kernel 16 --tail conv_stem_pool7_i8_kernel 1 --tail quantize_pad_nhwc4 1 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
+python3 tools/pmc_summary.py --tail conv_chain_i8_kernel 11 --tail conv_i8_mfma_kernel 6 --tail conv3x3_halo_i8_kernel 16 --tail conv_pwr_i8_kernel 4 --tail conv_stem_pool7_i8_kernel 1 --tail quantize_pad_nhwc4 1 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
 python3 tools/plan_profile.py resnet50 512 > "$OUT/plan_profile_resnet50_b512.txt" 2>&1
 python3 tools/plan_profile.py repvgg_a1 512 > "$OUT/plan_profile_repvgg_a1_b512.txt" 2>&1
 python3 tools/plan_profile.py mobileone_s1 1024 > "$OUT/plan_profile_mobileone_s1_b1024.txt" 2>&1
