@@ -148,6 +148,8 @@ RES_CASES = [
     (128, 7, 7, 512, 2048, True, True, 0.0, True),        # stage 4 (fp32 block output + codes), codes handed on re-centred
     (96, 7, 7, 512, 2048, False, False, 5.0, False),      # 4 704 pixels = 147 blocks, a zero point
     (24, 14, 14, 256, 128, True, True, 0.0, False),       # one slice; 147 blocks: fewer than the waves of its workgroups
+    (64, 8, 8, 256, 4096, True, True, 0.0, False),        # the smallest pixel count (4 096) against the widest layer the kernel takes: 32 slices
+    (16, 16, 16, 512, 128, False, False, 2.0, True),      # 4 096 pixels, one slice, a zero point, re-centred emission
     (512, 14, 14, 256, 1024, False, True, 0.0, False),    # BASELINE configs[2] at its stated size: the two shapes of the ResNet-50 plan at batch 512
     (512, 7, 7, 512, 2048, True, True, 0.0, False),
 ]
