@@ -85,6 +85,18 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_model_name():
+    """The host CPU's model string (BASELINE.md section 3 promises it beside the core count)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def cpu_baseline(batch, budget_s=16.0, fold_bn=True, halfnormal=True):
     """The reference's CPU path (port in oracle/ref_layers.py) on a bounded sample of the same workload: all granted
     cores (the headline `value`, from the median forward) and one thread, median and min of the timed forwards."""
@@ -124,7 +136,7 @@ def cpu_baseline(batch, budget_s=16.0, fold_bn=True, halfnormal=True):
         t1 = timed(budget_s / 2, 5)
         torch.set_num_threads(cores)
     med, med1 = statistics.median(ts), statistics.median(t1)
-    return {"value": round(batch / med, 2), "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": round(batch / med, 2), "unit": "images/s", "cores": cores, "cpu_model": cpu_model_name(), "kind": "port",
             "sample": f"{len(ts)} forwards of batch {batch} (same ResNet-50 W8A8 layer stack, torch {torch.__version__} CPU, "
                       f"{cores} threads), after 1 calibration forward; value = batch / median forward time",
             "median_ms": round(med * 1e3, 1), "min_ms": round(min(ts) * 1e3, 1),
@@ -220,6 +232,50 @@ def family_roofline(tag, f):
     return {"bound": b, "achieved": r[b]["achieved"], "peak": r[b]["peak"], "unit": r[b]["unit"], "frac": r[b]["frac"], "traffic": None, **r}
 
 
+def pmc_traffic(kernel_substr, launches, algorithmic, pattern="*pmc_bench_fused_plan*.json"):
+    """HBM bytes per launch of a kernel family from the committed PMC passes of this same command, run with --no-other-configs
+    (profiles/*pmc_bench*.json, made by tools/pmc_summary.py --tail; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    16-byte-per-lane streaming reads on gfx950).  A TAIL entry is used only if it describes THIS step's launches: its dispatch
+    count must equal the family's launches per step, and its bytes must not be below 0.9 x the family's algorithmic bytes (round 4's
+    file held the side networks' dispatches for two families: less traffic than the layers' own operands - refused now, with the reason).
+    Returns (bytes, file, reason-if-refused)."""
+    import glob
+    why = f"no profiles/{pattern} with a TAIL entry for this kernel"
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pattern)), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for k, v in d.items():
+            if k.startswith("TAIL") and kernel_substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                got = int((2 * v["FETCH_SIZE"]["mean_KiB"] + v["WRITE_SIZE"]["mean_KiB"]) * 1024)
+                n = (v["FETCH_SIZE"]["dispatches"], v["WRITE_SIZE"]["dispatches"])
+                if n != (launches, launches):
+                    why = f"{os.path.basename(path)}: TAIL holds {n} dispatches, the step has {launches} launches of this kernel"
+                elif algorithmic and got < 0.9 * algorithmic:
+                    why = (f"{os.path.basename(path)}: TAIL reads {got} B per launch, below 0.9 x the {algorithmic} algorithmic bytes - "
+                           "not this step's launches; not reported")
+                else:
+                    return got, os.path.basename(path), None
+    return None, None, why
+
+
+def side_roofline(name, tag, f):
+    """A side network's roofline object with the HBM traffic of ITS launches (profiles/*pmc_bench_<name>.json: rocprofv3 passes of
+    `bench.py --model <name>`, tools/collect_profiles.sh), under the same plausibility rule as the headline's."""
+    r = family_roofline(tag, f)
+    kern = FAMILY_KERNEL.get(tag, tag).split(" ")[0]
+    got, src, why = pmc_traffic(kern, f["launches"], f["bytes"] // max(f["launches"], 1), f"*pmc_bench_{name}*.json")
+    r["traffic"] = got
+    r["traffic_measured_in_run"] = False
+    if src:
+        r["traffic_source"] = f"profiles/{src}"
+        r["traffic_over_algorithmic"] = round(got / max(f["bytes"] // max(f["launches"], 1), 1), 4)
+    else:
+        r["traffic_unavailable"] = why
+    return r
+
+
 def side_config(name, batch, args, dev, world, rank, barrier):
     """One more network of BASELINE.json through the same pipeline as the headline (calibrating forward, frozen plan, K steps
     bracketed by barrier + synchronize, MAX over ranks): repvgg_a1 = configs[3]'s network at its 512 images per GPU (FSPTQ W8A8,
@@ -269,8 +325,51 @@ def side_config(name, batch, args, dev, world, rank, barrier):
             "unit": "images/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup, "batch_per_gpu": batch,
             "config": ("BASELINE configs[4]: W minmax_channel u4 asymmetric per channel (QBase family), A minmax_tensor u8, packed int4 weights"
                        if w4a8 else "BASELINE configs[3]'s network at its per-GPU batch: FSPTQ W minmax_channel s8, A minmax_tensor u8, deploy form"),
-            "roofline": family_roofline(top, fam[top]),
+            "roofline": side_roofline(name, top, fam[top]),
             "families_ms": {k: round(f["ms"], 3) for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
+
+
+def fake_quant_leg(args, dev, x, steps=3):
+    """north_star's literal bar on the headline model: the SAME network with every wrapper on its own (`--conv fp32 --plan modules`:
+    per layer one stand-alone fake-quant launch for the activations and one for the weights - fq_tensor_kernel / fq_channel_kernel, 4 B read
+    + 4 B written per element: SURVEY.md 8(d)'s 43.9 GB per step at batch 512 - then MIOpen's fp32 convolution of the fake-quantised
+    operands, the reference's own op sequence), `steps` forwards with HIP events on every fake-quant launch after one calibrating
+    forward.  The roofline object is algorithmic bytes / summed launch time of those kernels alone; the convolutions in between are not in it."""
+    import workloads as W
+    from dlmc.quantization.scalar import kernels as K
+    from dlmc.utils.quantize import quantize_model
+    torch.manual_seed(2333)
+    model = W.MODELS[args.model]().to(dev).eval()
+    if not args.keep_bn:
+        from dlmc.utils.merge_bn import merge_bn
+        model = merge_bn(model, inplace=True, allow_missing=True)
+    quantize_model(model, json.loads(json.dumps(QCFG)), None, quantization_type="FSPTQ", int8_gemm=False)
+    with torch.no_grad():
+        model(x)                     # calibration, untimed
+        model(x)                     # warm-up (MIOpen's algorithm search)
+        torch.cuda.synchronize()
+        K.PROFILE.reset()
+        K.PROFILE.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(x)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        K.PROFILE.enabled = False
+    fam = {k: f for k, f in families(K.PROFILE.records).items() if k.startswith("fq") and f["ms"] > 0}
+    K.PROFILE.reset()
+    nbytes, ms, launches = sum(f["bytes"] for f in fam.values()), sum(f["ms"] for f in fam.values()), sum(f["launches"] for f in fam.values())
+    gbps = nbytes / (ms * 1e-3) / 1e9 if ms else 0.0
+    del model
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+            "kernel": "fq_tensor_kernel<ZEROPOINT> + fq_channel_kernel<SYMMETRIC> (stand-alone fake-quant of every layer's input and weight)",
+            "launches_per_step": launches // steps, "algorithmic_bytes_per_step": nbytes // steps, "fake_quant_ms_per_step": round(ms / steps, 3),
+            "whole_step_ms": round(wall / steps * 1e3, 2), "steps": steps,
+            "families": {k: {"launches": f["launches"] // steps, "GBps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1)} for k, f in fam.items()},
+            "note": f"{args.model} batch {args.batch} in `--conv fp32 --plan modules` form (the reference's op sequence: fake-quant launches + fp32 "
+                    "convolutions), same process, after the headline region; bytes = 8 per fake-quantised element (SURVEY.md 8(d): 43.9 GB per "
+                    "step for ResNet-50 at batch 512), time = the fake-quant launches' HIP events summed; north_star's >= 0.70 is about this figure"}
 
 
 def collective_report(dev, world, backend, calib_allreduces, reps=54):
@@ -345,6 +444,9 @@ def main():
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
                     help="default model only: skip the short RepVGG-A1 b512 / MobileOne-S1 b1024 runs reported under `other_configs`")
     ap.add_argument("--other-steps", type=int, default=50, help="timed steps of each `other_configs` run (10 warm-up steps)")
+    ap.add_argument("--no-fake-quant-leg", dest="fq_leg", action="store_false",
+                    help="skip `roofline_fake_quant_resnet50`: three forwards of the same model in `--conv fp32 --plan modules` form behind the "
+                         "headline region (the stand-alone fake-quant kernels' own roofline on the whole network)")
     args = ap.parse_args()
     args.int8 = args.conv == "int8"
     if args.batch is None:
@@ -501,21 +603,6 @@ def main():
             r["note"] = note
         return r
 
-    def pmc_traffic(kernel_substr):
-        """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-        (profiles/*pmc_bench*.json, made by tools/pmc_summary.py --tail; FETCH_SIZE doubled as MI355X_MICROARCH.md
-        prescribes for 16-byte-per-lane streaming reads on gfx950).  None when no such file travels with the repo."""
-        import glob
-        for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_bench*.json")), reverse=True):
-            try:
-                d = json.load(open(path))
-            except (OSError, ValueError):
-                continue
-            for k, v in d.items():
-                if k.startswith("TAIL") and kernel_substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                    return int((2 * v["FETCH_SIZE"]["mean_KiB"] + v["WRITE_SIZE"]["mean_KiB"]) * 1024), os.path.basename(path)
-        return None, None
-
     empty = {"launches": 0, "bytes": 0, "ms": 0.0, "ops": 0}
     fq = fam.get("fq_tensor", empty)
     fq_roof = roof("fq_tensor", fq, "fq_tensor_kernel<ZEROPOINT> (per-tensor activation fake-quant"
@@ -569,10 +656,13 @@ def main():
         for r in (main_roof, second_roof, third_roof, fourth_roof):
             if r is None:
                 continue
-            r["traffic"], src = pmc_traffic(r["kernel"].split(" ")[0])
+            r["traffic"], src, why = pmc_traffic(r["kernel"].split(" ")[0], r["launches"] // psteps, r["algorithmic_bytes_per_launch_avg"])
             r["traffic_measured_in_run"] = False
             if src:
-                r["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"
+                r["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command with --no-other-configs)"
+                r["traffic_over_algorithmic"] = round(r["traffic"] / max(r["algorithmic_bytes_per_launch_avg"], 1), 4)
+            else:
+                r["traffic_unavailable"] = why
     if args.fused:
         # In the fused plan the activation quantiser lives in the conv epilogue, so the stand-alone fake-quant kernel
         # hardly appears in the step.  Its own roofline is measured here, live, on BASELINE configs[1]'s tensor
@@ -655,6 +745,8 @@ def main():
                           "peak_TOPs_dense_i8": MFMA_I8_PEAK_TOPS}
     if coll is not None:
         out["collective"] = coll
+    if args.fq_leg and args.fused and args.model == "resnet50" and world == 1:
+        out["roofline_fake_quant_resnet50"] = fake_quant_leg(args, dev, x)
     other = other_configs()
     if other is not None:
         out["other_configs"] = other

@@ -513,6 +513,8 @@ extern "C" int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* ou
   if (N < 0 || H < 1 || W < 1 || C < 4 || (C & 3) || R < 1 || S < 1 || R > 7 || S > 7 || stride < 1 || pad < 0) return DLMCQ_EINVAL;
   const int64_t P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
   if (P < 1 || Q < 1) return DLMCQ_EINVAL;
+  const uint32_t ctl = (uint32_t)q_form & (DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY);     // (include/dlmcq.h: control bits of `q_form`)
+  q_form &= ~(DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY);
   if (N == 0) return DLMCQ_OK;
   if (!x || !w || !(out || codes) || !in_scale || !w_scale) return DLMCQ_EINVAL;
   if (codes && (!q_scale || q_lo > q_hi || q_lo < -128 || q_hi > 255 || q_hi - q_lo > 255 || q_form < DLMCQ_FORM_EMULATE ||
@@ -540,9 +542,12 @@ extern "C" int dlmcq_conv2d_dw_i8_nhwc(const void* x, const int8_t* w, float* ou
   const int64_t total = N * P * Q * (C / 4);
   const int64_t blocks = (total + DLMCQ_BLOCK - 1) / DLMCQ_BLOCK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (conv_dwm_applies(N, H, W, C, R, S, stride, pad, ep, out, x))      // codes-only 3 x 3 / 1 / 1 layers: the multiply-adds on the matrix cores
+  if (!(ctl & DLMCQ_FORCE_TILED) && conv_dwm_applies(N, H, W, C, R, S, stride, pad, ep, out, x)) {   // codes-only 3 x 3 / 1 / 1 layers: the multiply-adds on the matrix cores
+    if (ctl & DLMCQ_ROUTE_ONLY) return DLMCQ_ROUTE_DWM;
     return conv_dwm_launch(static_cast<const int8_t*>(x), w, bias, in_scale, in_zero_point, w_scale, w_offset, N, H, W, C,
                            x_is_unsigned ? 0 : 1, ep, st);
+  }
+  if (ctl & DLMCQ_ROUTE_ONLY) return DLMCQ_ROUTE_DW;
   const bool wide = R == 3 && S == 3 && C % 16 == 0 && C <= 2048 && aligned16(x) && (!codes || aligned16(codes));
   if (wide && stride == 1 && pad == 1 && C <= 1024) {     // two output pixels per thread (LDS: 48 B per channel)
     g.cdiv = make_fastdiv((uint32_t)(C / 16));

@@ -25,12 +25,14 @@ struct ConvEpi {
   int q_form;
   int relu;
   uint32_t q_xor;          // 0x80808080 when the codes are stored as int8 `code - 128` (DLMCQ_EMIT_SHIFT128), else 0
+  uint32_t ctl;            // host side only: DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY as passed in `q_form`
 };
 
 // `q_form` argument of an entry point -> (form, shifted-emission flag); false = invalid
 static inline bool epi_set_form(ConvEpi& ep, int32_t q_form, int32_t q_lo, int32_t q_hi) {
   const bool shifted = (q_form & DLMCQ_EMIT_SHIFT128) != 0;
-  ep.q_form = q_form & ~DLMCQ_EMIT_SHIFT128;
+  ep.ctl = (uint32_t)q_form & (DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY);
+  ep.q_form = q_form & ~(DLMCQ_EMIT_SHIFT128 | DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY);
   ep.q_xor = shifted ? 0x80808080u : 0u;
   return ep.q_form >= DLMCQ_FORM_EMULATE && ep.q_form <= DLMCQ_FORM_SYMMETRIC && (!shifted || (q_lo >= 0 && q_hi <= 255));
 }

@@ -691,12 +691,17 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   // ... and widths of 192, 576, ... (no multiple of 128) 192-wide ones - codes-only layers with the swapped epilogue (MobileOne-S1's
   // 192 -> 192 layers at 28^2: one tile column fewer, a third fewer re-reads of the activations)
   if (!forced && ep.w_off && plan.bn == 64 && K % 192 == 0 && plan.swap && ep.codes && !out && !ep.residual && aligned16(ep.codes)) plan.bn = 192;
-  if (plan.halo && conv_pw_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
-    return conv_pw_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, shift, ep, st);
-  if (plan.halo && conv_pwr_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2))
-    return conv_pwr_launch(xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st, seg2);
-  if (plan.halo && conv3x3_halo_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
-    return conv3x3_halo_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st);
+  // the specialised kernels, unless the caller (DLMCQ_FORCE_TILED) or a lab plan keeps the call on this file's kernel;
+  // DLMCQ_ROUTE_ONLY: the decision is the answer, nothing is launched
+  const bool special = plan.halo && !(ep.ctl & DLMCQ_FORCE_TILED), route_only = (ep.ctl & DLMCQ_ROUTE_ONLY) != 0;
+  if (special && conv_pw_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
+    return route_only ? DLMCQ_ROUTE_PW : conv_pw_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, shift, ep, st);
+  if (special && conv_pwr_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2))
+    return route_only ? DLMCQ_ROUTE_PWR
+                      : conv_pwr_launch(xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st, seg2);
+  if (special && conv3x3_halo_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
+    return route_only ? DLMCQ_ROUTE_HALO3X3
+                      : conv3x3_halo_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st);
   // 256-wide tiles exist for the swapped codes-only layers only (one third fewer operand bytes per MAC, two workgroups per CU)
   const bool swap_ok = plan.swap && ep.codes && !out && !ep.residual && K % plan.bn == 0 && aligned16(ep.codes);
   // (192-wide tiles: the swapped asymmetric codes-only instantiation is the only one - a forced plan that asks for them anywhere
@@ -720,6 +725,7 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
     s2.g.nblk_n = g.nblk_n;
     if (s2.g.M != g.M || s2.g.K != g.K || s2.g.P != g.P || s2.g.Q != g.Q || ep.w_off) return DLMCQ_EINVAL;
   }
+  if (route_only) return DLMCQ_ROUTE_TILED;
 #define DLMCQ_CONV_ARGS dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, s2
   if (seg2) {
     if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, true, true>), DLMCQ_CONV_ARGS);

@@ -276,13 +276,24 @@ __global__ __launch_bounds__(NW * 64, PW_WPS(C, BN)) void conv_pw_i8_kernel(PwAr
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the requests past the end: nothing may be in flight into registers at s_endpgm)
 }
 
+// The (input channels, slice width) pairs the kernel is instantiated for - ONE table for conv_pw_applies and conv_pw_launch (round 4's
+// predicate admitted e.g. 128 -> 64 or 512 -> 192, which the launch table did not hold: conv_launch then returned DLMCQ_EINVAL for a
+// layer the tiled kernel used to take).  A K-wide layer is cut into slices of pw_slice(K) output channels.
+#define DLMCQ_PW_PAIRS(X) X(64, 64) X(64, 128) X(64, 192) X(128, 128) X(128, 192) X(192, 128) X(192, 192) X(512, 128) X(1024, 128)
+constexpr int pw_slice(int64_t K) { return K == 192 ? 192 : (K == 64 ? 64 : (K % 128 == 0 ? 128 : 0)); }
+constexpr bool pw_built(int64_t C, int bn) {
+#define DLMCQ_PW_HAS(CC, BB) if (C == CC && bn == BB) return true;
+  DLMCQ_PW_PAIRS(DLMCQ_PW_HAS)
+#undef DLMCQ_PW_HAS
+  return false;
+}
+
 // where the kernel applies: codes in, codes out, nothing else attached; the widths MobileOne-S1 uses
 bool conv_pw_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
                      int32_t dilation, const ConvEpi& ep, const float* out, bool dual) {
   if (R != 1 || S != 1 || stride != 1 || pad != 0 || dilation != 1 || dual || out || ep.residual || !ep.codes) return false;
   if (!epi_plain(ep)) return false;                             // (other quantisers: the tiled kernel)
-  if (!(C == 64 || C == 128 || C == 192 || C == 512 || C == 1024)) return false;
-  if (!(K == 64 || K == 192 || K % 128 == 0) || K > 1024) return false;
+  if (K > 1024 || !pw_built(C, pw_slice(K))) return false;       // (exactly the (C, slice) pairs conv_pw_launch instantiates)
   if (!aligned16(ep.codes)) return false;
   const int64_t M = N * H * W;
   if (M < 4096) return false;                                   // (the weights are loaded once per workgroup: a few blocks per wave at least)
@@ -335,7 +346,7 @@ int conv_pw_launch(const int8_t* x, const int8_t* w, const float* bias, const in
   a.M = (int)(N * H * W); a.K = (int)K; a.shift = shift;
   a.nblk = (a.M + 31) / 32;
   const bool asym = ep.w_off != nullptr;
-  const int bn = K == 192 ? 192 : (K == 64 ? 64 : 128);
+  const int bn = pw_slice(K);
 #ifdef DLMCQ_LAB
 #define DLMCQ_PWL(CC, BB, L) \
   if (C == CC && bn == BB && lab == L && asym) return pw_go<CC, BB, true, L>(a, ep, st)
@@ -349,16 +360,8 @@ int conv_pw_launch(const int8_t* x, const int8_t* w, const float* bias, const in
 #endif
   if (lab) return DLMCQ_EINVAL;
 #define DLMCQ_PW(CC, BB)                                         \
-  if (C == CC && bn == BB) return asym ? pw_go<CC, BB, true>(a, ep, st) : pw_go<CC, BB, false>(a, ep, st)
-  DLMCQ_PW(64, 64);
-  DLMCQ_PW(64, 128);
-  DLMCQ_PW(64, 192);
-  DLMCQ_PW(128, 128);
-  DLMCQ_PW(128, 192);
-  DLMCQ_PW(192, 128);
-  DLMCQ_PW(192, 192);
-  DLMCQ_PW(512, 128);
-  DLMCQ_PW(1024, 128);
+  if (C == CC && bn == BB) return asym ? pw_go<CC, BB, true>(a, ep, st) : pw_go<CC, BB, false>(a, ep, st);
+  DLMCQ_PW_PAIRS(DLMCQ_PW)
 #undef DLMCQ_PW
   return DLMCQ_EINVAL;
 }

@@ -1,3 +1,17 @@
+// LAB VARIANT, NOT BUILT (round 5): csrc/conv_chain_i8.hip with chunk 0's requests issued BEHIND the input tile's DMA and in flight while
+// the wave waits for the tile (one memory round trip at a tile's start instead of two: the trace had "A loaded" 2.5 - 4.9 k clocks followed by
+// "c0 ready" 3.8 - 7 k, up to 30 % of a 56^2 tile's life), every uniform parameter read by asm scalar loads and GEMM 2's per-channel constants
+// by LDS-DMA so that no compiler-inserted `s_waitcnt vmcnt(0)` drains the queue in between.  Bit-identical (tests/test_gpu_chain.py, equal
+// checksums in tools/chain_ab.py), lint-clean - and NO faster: same box, old / new / old / new, the plan's 11 launches 3786 / 3765 / 3759 /
+// 3829 us (56^2 mid-stage 604 -> 623 / 599 -> 655, 28^2 stage end 290 -> 281 / 285 -> 274, everything else +-1 %; gpurun_out r5e, LABNOTES
+// section 14).  A workgroup's start-up latency is not what a CU's throughput hangs on: the other workgroups of the CU fill it.  Kept for the
+// record; to build it, copy it over csrc/conv_chain_i8.hip (it needs sload_issue / sload_wait and the EpiQuant(ep, scale, zp, fold)
+// constructor at the end of this file's comment block - both removed from the headers again).
+//
+//   __device__ __forceinline__ uint32_t sload_issue(const void* p) { uint32_t v; asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory"); return v; }
+//   __device__ __forceinline__ void sload_wait(uint32_t& a, ..., uint32_t& h) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), ..., "+s"(h)::"memory"); }
+//   EpiQuant(const ConvEpi& ep, float s, float z, bool fold_relu): the constructor body with `s`, `z` in place of ep.q_scale[0], ep.q_zp[0]
+//
 // A residual block's LAST 1x1 convolution (+ shortcut + ReLU + the consumer's quantiser) and the NEXT block's FIRST 1x1
 // convolution (+ ReLU + its consumer's quantiser) as ONE kernel.  (FSPTQuant/base.py:95-159 twice, with the `out += identity;
 // relu` of the model between them; same arithmetic, same order as conv_i8.hip's kernel run twice: bit-identical.)
@@ -108,9 +122,8 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   constexpr int TF = DLMCQ_CHAIN_LDS_T;
   constexpr bool LDST = TF != 0;
 #ifdef DLMCQ_LAB
-  // lab builds of the shapes with LDS to spare carry a 16 KB landing area for the timing-only variant `lab & 0x800` (round 5: the
-  // shortcut tile by LDS-DMA instead of loads into registers - does the stream itself move differently?  56^2 mid-stage -1.7 %, 56^2
-  // stage end +3.5 %: no.  LABNOTES 14)
+  // lab builds of the two shapes with LDS to spare carry a 16 KB landing area for the timing-only variant `lab & 0x800` (round 5: the
+  // shortcut tile by LDS-DMA instead of loads into registers - does the stream itself move differently?)
   constexpr int LABDMA = (C2 == 0 && C1 == 64) ? 16384 : 0;
 #else
   constexpr int LABDMA = 0;
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 #ifdef DLMCQ_LAB
   // timing only (round 5): are the chip's workgroups in lockstep?  Workgroups of the FIRST round start late - 0x200: the second
   // workgroup of a CU (blockIdx 256 .. 511) by `lab >> 16` units of 64 clocks; 0x400: every workgroup by a hashed 0 .. 15 sixteenths
-  // of that (later rounds inherit the offsets: a slot's next tile starts when its last one ends).  Measured: -1 .. -4 % at best (LABNOTES 14)
+  // of that (later rounds inherit the offsets: a slot's next tile starts when its last one ends)
   if ((a.lab & 0x600) && blockIdx.x < 512) {
     const int unit = a.lab >> 16;
     const int d = (a.lab & 0x200) ? ((blockIdx.x >> 8) & 1) * unit : (int)(((blockIdx.x * 2654435761u) >> 28) * (uint32_t)unit) >> 4;
@@ -152,6 +165,37 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   }
 #endif
 
+  // GEMM 2's epilogue constants are read first of all: the compiler waits for these loads where their values are written to LDS (below,
+  // behind the tile's and chunk 0's requests), and a wait for the OLDEST operations of the queue lets everything younger stay in flight
+  // (scalar parameters first: asm scalar loads - conv_i8_common.h - of every uniform value the kernel reads through a pointer, one wait)
+  uint32_t u_sin1 = sload_issue(a.s_in1), u_zp1 = sload_issue(a.zp_in1 ? a.zp_in1 : a.s_in1);
+  uint32_t u_sin1b = sload_issue(DUALH ? a.s_in2 : a.s_in1), u_zp1b = sload_issue((DUALH && a.zp_in2) ? a.zp_in2 : a.s_in1);
+  uint32_t u_qs1 = sload_issue(ep1.q_scale), u_qz1 = sload_issue(ep1.q_zp ? ep1.q_zp : ep1.q_scale);
+  uint32_t u_qs2 = sload_issue(ep2.q_scale), u_qz2 = sload_issue(ep2.q_zp ? ep2.q_zp : ep2.q_scale);
+  sload_wait(u_sin1, u_zp1, u_sin1b, u_zp1b, u_qs1, u_qz1, u_qs2, u_qz2);
+  const float sin2 = __builtin_bit_cast(float, u_qs1);     // GEMM 2's input scale IS the quantiser the codes were made with
+  const float zpf2 = ep1.q_zp ? __builtin_bit_cast(float, u_qz1) : 0.0f;
+  const int dz2 = 128 - (int)__builtin_rintf(zpf2);
+  // (their per-channel operands - scale, code sum, bias of the KB output channels - come by LDS-DMA like everything else: a
+  //  compiler-known vector load anywhere behind the first DMA gets `s_waitcnt vmcnt(0)` - the whole queue - at its use.  4-byte
+  //  pieces, 64 channels per wave-instruction, dealt over the waves; a missing bias reads the scales and is ignored)
+  {
+    constexpr int NP3 = (3 * U3 + 3) / 4;                  // pieces per wave (a wave past the end repeats the last piece: same bytes)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int i = 0; i < NP3; ++i) {
+      const int j = (i * 4 + wv < 3 * U3) ? i * 4 + wv : 3 * U3 - 1;
+      const int arr = j / U3, seg = j % U3;
+      const int32_t* const sp = arr == 0 ? reinterpret_cast<const int32_t*>(a.s_w3)
+                                         : (arr == 1 || !a.bias3) ? (arr == 1 ? a.wsum3 : reinterpret_cast<const int32_t*>(a.s_w3))
+                                                                  : reinterpret_cast<const int32_t*>(a.bias3);
+      __builtin_amdgcn_global_load_lds((gptr_t)(sp + seg * 64 + lane), (lptr_t)(par3 + arr * KB * 4 + seg * 256), 4, 0, 0);
+    }
+  }
+  const float sin1 = __builtin_bit_cast(float, u_sin1);
+  const float zpf1 = a.zp_in1 ? __builtin_bit_cast(float, u_zp1) : 0.0f;
+  const float sin1b = DUALH ? __builtin_bit_cast(float, u_sin1b) : 0.0f;
+  const float zpf1b = (DUALH && a.zp_in2) ? __builtin_bit_cast(float, u_zp1b) : 0.0f;
   // ---- The tile's input rows (rows beyond the tile read its last row: never stored) go to LDS by LDS-DMA, 16 rows x 64 B per
   // wave-instruction, into buffer 1 of the weight double buffer - in W1's (W2's) own unit layout and swizzle, so the fragment
   // reads below are GEMM 1's weight-fragment reads with another base.  (Round 3: the fragments used to be loaded straight into
@@ -174,45 +218,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
         __builtin_amdgcn_global_load_lds((gptr_t)(xp2 + s * 64), (lptr_t)(lds + WCH + (S1 + s) * 4096 + (tid >> 6) * 1024), 16, 0, 0);
     }
   }
-  // GEMM 2's epilogue constants, once per workgroup (its accumulator is kept with the operands swapped - weights as A, the
-  // code tile as B - so a lane owns 16 consecutive channels of one pixel and reads their constants as broadcast ds_read_b128)
-  const float sin2 = ep1.q_scale[0];                       // GEMM 2's input scale IS the quantiser the codes were made with
-  const float zpf2 = ep1.q_zp ? ep1.q_zp[0] : 0.0f;
-  const int dz2 = 128 - (int)__builtin_rintf(zpf2);
-  if (tid < KB) {
-    reinterpret_cast<float*>(par3)[tid] = sin2 * a.s_w3[tid];
-    reinterpret_cast<int*>(par3)[KB + tid] = dz2 * a.wsum3[tid];
-    reinterpret_cast<float*>(par3)[2 * KB + tid] = a.bias3 ? a.bias3[tid] : 0.0f;
-  }
-  // the input tile has landed, and no compiler-known load is outstanding from here on (the counted waits below assume it)
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   i32x4 af[S1][2];
-  i32x4 af2[DUALH ? S2 : 1][2];
-  {
-    const int r = wr * 32 + l31;
-    const int8_t* ab = lds + WCH + r * 64;
-    const uint32_t xw = a.shift1 ? 0x80808080u : 0u;
-#pragma unroll
-    for (int s = 0; s < S1; ++s)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const i32x4 t = *reinterpret_cast<const i32x4*>(ab + s * 4096 + (((ks * 2 + hsel) ^ ((r >> 2) & 3)) << 4));
-        af[s][ks] = i32x4{(int)(t.x ^ xw), (int)(t.y ^ xw), (int)(t.z ^ xw), (int)(t.w ^ xw)};
-      }
-    if constexpr (DUALH) {
-      const uint32_t xw2 = a.shift2 ? 0x80808080u : 0u;
-#pragma unroll
-      for (int s = 0; s < S2; ++s)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const i32x4 t = *reinterpret_cast<const i32x4*>(ab + (S1 + s) * 4096 + (((ks * 2 + hsel) ^ ((r >> 2) & 3)) << 4));
-          af2[s][ks] = i32x4{(int)(t.x ^ xw2), (int)(t.y ^ xw2), (int)(t.z ^ xw2), (int)(t.w ^ xw2)};
-        }
-    }
-  }
-  // (the fragments are in registers before this wave reaches chunk 0's barrier, behind which buffer 1 is requested for chunk 1)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  CHAIN_STAMP();   // 1: A fragments in registers
 
   // ---- addressing of the fp32 tile in the transposed (row-major) layout: group g -> row wr*32 + 8g + 4 hsel + b4 ----
   const uint32_t fbytes = (uint32_t)((int64_t)a.M * a.KD * 4);
@@ -320,16 +326,13 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     }
   };
 
-  const float sin1 = a.s_in1[0];
-  const float zpf1 = a.zp_in1 ? a.zp_in1[0] : 0.0f;
   const int dz1 = a.shift1 - (int)__builtin_rintf(zpf1);
-  const float sin1b = DUALH ? a.s_in2[0] : 0.0f;
-  const int dz1b = DUALH ? a.shift2 - (int)__builtin_rintf(a.zp_in2 ? a.zp_in2[0] : 0.0f) : 0;
+  const int dz1b = DUALH ? a.shift2 - (int)__builtin_rintf(zpf1b) : 0;
   ConvEpi e1 = ep1;
   e1.codes = reinterpret_cast<uint8_t*>(uintptr_t(1));   // the quantiser is always needed (GEMM 2 reads its codes)
   // FL >= 0 also says: both quantisers are the plain unsigned-byte one (epi_plain_q; the launcher checks) - code4n_plain, whose
   // saturating pack is the ReLU as far as the codes are concerned
-  const EpiQuant eq1(e1, FL >= 0);
+  const EpiQuant eq1(e1, sin2, zpf2, FL >= 0);            // (its scale and zero point were read at the kernel's top)
   __builtin_assume(!eq1.sgn);                            // (the range is [0, 255]: chain_launch refuses anything else)
 
   i32x16 acc2[U3];
@@ -339,6 +342,51 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     for (int i = 0; i < 16; ++i) acc2[j][i] = 0;
 
   request(0, std::integral_constant<int, 0>{});
+
+  // ---- Round 5: chunk 0's requests are in flight BEHIND the input tile's (issued at the kernel's top) while this wave waits for the
+  // tile: one memory round trip at a tile's start instead of two (the trace had "A loaded" 2.5 - 4.9 k clocks and then "c0 ready" 3.8 -
+  // 7 k, a quarter of a 56^2 tile's life).  GEMM 2's epilogue constants, once per workgroup (its accumulator is kept with the operands
+  // swapped - weights as A, the code tile as B - so a lane owns 16 consecutive channels of one pixel and reads their constants as
+  // broadcast ds_read_b128): requested at the top, finished below.
+  // the input tile has landed (everything request(0) issued - NREQ0 operations per wave, the same number in every wave - may still be
+  // in flight), and no compiler-known load is outstanding from here on (the counted waits below assume it)
+  constexpr int NREQ0 = S1 + U3 + 1 + (DUALH ? S2 + 1 : 4);
+#ifdef DLMCQ_LAB
+  if (a.lab & 0x3f) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");    // (the ablations issue fewer)
+  else
+#endif
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NREQ0) : "memory");
+  if (tid < KB) {       // (in place, each thread its own three words; read again only behind the chunk loop's barriers)
+    reinterpret_cast<float*>(par3)[tid] = sin2 * reinterpret_cast<const float*>(par3)[tid];
+    reinterpret_cast<int*>(par3)[KB + tid] = dz2 * reinterpret_cast<const int*>(par3)[KB + tid];
+    if (!a.bias3) reinterpret_cast<float*>(par3)[2 * KB + tid] = 0.0f;
+  }
+  i32x4 af2[DUALH ? S2 : 1][2];
+  {
+    const int r = wr * 32 + l31;
+    const int8_t* ab = lds + WCH + r * 64;
+    const uint32_t xw = a.shift1 ? 0x80808080u : 0u;
+#pragma unroll
+    for (int s = 0; s < S1; ++s)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const i32x4 t = *reinterpret_cast<const i32x4*>(ab + s * 4096 + (((ks * 2 + hsel) ^ ((r >> 2) & 3)) << 4));
+        af[s][ks] = i32x4{(int)(t.x ^ xw), (int)(t.y ^ xw), (int)(t.z ^ xw), (int)(t.w ^ xw)};
+      }
+    if constexpr (DUALH) {
+      const uint32_t xw2 = a.shift2 ? 0x80808080u : 0u;
+#pragma unroll
+      for (int s = 0; s < S2; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const i32x4 t = *reinterpret_cast<const i32x4*>(ab + (S1 + s) * 4096 + (((ks * 2 + hsel) ^ ((r >> 2) & 3)) << 4));
+          af2[s][ks] = i32x4{(int)(t.x ^ xw2), (int)(t.y ^ xw2), (int)(t.z ^ xw2), (int)(t.w ^ xw2)};
+        }
+    }
+  }
+  // (the fragments are in registers before this wave reaches chunk 0's barrier, behind which buffer 1 is requested for chunk 1)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  CHAIN_STAMP();   // 1: A fragments in registers
 
   auto chunk = [&](int n, auto par_c) {
     constexpr int P = decltype(par_c)::value;
@@ -478,7 +526,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   // ---- epilogue 2: the reduction layer's own dequantise, ReLU, its consumer's quantiser; codes only.  Lane (p = l31, hsel) holds
   // channels wc * KB/2 + 32 j + 16 hsel + 0..15 of pixel wr * 32 + p: no transposition, the ReLU folded into the quantiser's clamp
   // (code(relu(v)) = max(code(v), code(0))), 16 finished bytes per lane and block ----
-  const EpiQuant eq2(ep2, ep2.relu != 0);
+  const EpiQuant eq2(ep2, __builtin_bit_cast(float, u_qs2), ep2.q_zp ? __builtin_bit_cast(float, u_qz2) : 0.0f, ep2.relu != 0);
   const int lr2 = wr * 32 + l31;
 #pragma unroll
   for (int j = 0; j < U3; ++j) {
@@ -541,17 +589,7 @@ static int chain_launch(ChainArgs& a, int64_t M, int64_t C, int64_t K, int64_t C
   a.trace = g_chain_trace;
   a.lab = g_chain_lab;
 #endif
-  // Tile height: 64 rows.  A chunk costs a workgroup the same time at 32 .. 64 rows (round 5, tools/chain_ab.py --rows: a 14^2 launch takes
-  // 238 / 218 / 241 / 249 / 258 / 323 us at 64 / 56 / 49 / 48 / 40 / 32 rows, every other shape is fastest at 64), so shorter tiles only pay
-  // where they keep a nearly empty last round from costing a whole tile's life: ResNet-50's 14^2 chains at batch 512 - 1 568 tiles on the
-  // 512 slots of the two-workgroup instantiations, 3.06 rounds - run 3.5 rounds of 56-row tiles 8 % faster.  The rule: few rounds, the last
-  // one less than an eighth full.
-  if (rows_per_tile <= 0) {
-    const int64_t t64 = (M + 63) / 64, slots = 256 * CHAIN_WGS((int)(C + C2), (int)K2);
-    const int64_t full = t64 / slots, left = t64 % slots;
-    rows_per_tile = (full >= 2 && full <= 4 && left > 0 && left * 8 < slots) ? 56 : 64;
-  }
-  a.rows_per_tile = rows_per_tile;
+  a.rows_per_tile = rows_per_tile > 0 ? rows_per_tile : 64;   // (tile heights that fill the last round of workgroups exactly - 56, 49 - measured slower)
   if (a.rows_per_tile > 64) return DLMCQ_EINVAL;
   ep1.relu = relu != 0; ep1.q_scale = q_scale; ep1.q_zp = q_zero_point; ep1.q_lo = (float)q_lo; ep1.q_hi = (float)q_hi;
   ep1.q_g = q_ste_g; ep1.q_form = q_form; ep1.codes = static_cast<uint8_t*>(codes);

@@ -27,6 +27,11 @@ if LAB_OVERRIDE:
 FORM_EMULATE, FORM_QBASE, FORM_ZEROPOINT, FORM_SYMMETRIC, FORM_ROOTQ_ACT = range(5)
 EMIT_SHIFT128 = 0x100    # DLMCQ_EMIT_SHIFT128: OR-able into q_form (include/dlmcq.h)
 W2_CHUNK_MAJOR = 0x200   # DLMCQ_W2_CHUNK_MAJOR: OR-able into the chain entry points' last quantiser form
+FORCE_TILED = 0x400      # DLMCQ_FORCE_TILED: OR-able into q_form of conv2d_i8_nhwc_fused / _asym / _dual / conv2d_dw_i8_nhwc: the family's generic kernel
+ROUTE_ONLY = 0x800       # DLMCQ_ROUTE_ONLY: launch nothing, return which kernel the dispatch picks (ROUTE_*)
+ROUTE_TILED, ROUTE_HALO3X3, ROUTE_PW, ROUTE_PWR, ROUTE_DW, ROUTE_DWM = 1, 2, 3, 4, 5, 6
+ROUTE_TAG = {ROUTE_TILED: "conv_i8", ROUTE_HALO3X3: "conv3x3_halo", ROUTE_PW: "conv_pw", ROUTE_PWR: "conv_pwr", ROUTE_DW: "conv_dw",
+             ROUTE_DWM: "conv_dwm"}     # the profile tag (bench.py's kernel families) of each route
 Y_DEQUANT, Y_CODES = 0, 1
 CODES_NONE, CODES_I8, CODES_P4 = 0, 1, 2
 MINMAX_ABSMAX, MINMAX_MINMAX, MINMAX_NEGMIN = 0, 1, 2
@@ -142,6 +147,13 @@ class DlmcqError(RuntimeError):
 def check(rc):
     if rc != 0:
         raise DlmcqError(f"{lib.dlmcq_strerror(rc).decode()} (code {rc})")
+
+
+def route(rc):
+    """Return value of an entry point called with ROUTE_ONLY: the route (> 0), or an error like any other call."""
+    if rc <= 0:
+        raise DlmcqError(f"{lib.dlmcq_strerror(rc).decode()} (code {rc})" if rc < 0 else "route query returned DLMCQ_OK (an empty problem)")
+    return rc
 
 
 def stream_ptr():

@@ -408,7 +408,7 @@ class EmitCodes:
 
 
 def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1,
-              residual=None, relu=False, emit=None, want_out=True, w_offset=None):
+              residual=None, relu=False, emit=None, want_out=True, w_offset=None, force_tiled=False):
     """Fused int8 conv / linear on the matrix cores.  `codes`: uint8/int8 activation codes, logically
     (N, C, H, W) in channels_last memory, or (N, C) for a linear layer.  Returns fp32 (N, K, P, Q) in
     channels_last memory (or (N, K)).
@@ -416,7 +416,9 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
     Epilogue options (dlmcq_conv2d_i8_nhwc_fused): `residual` (fp32, the output's shape and layout) is added,
     `relu` applied, and with `emit=EmitCodes(...)` the consumer's activation codes of the result are written as
     well; the return value is then `(out, out_codes)`, `out` being None when `want_out=False`.
-    `w_offset` ([K] fp32): asymmetric per-channel weights w' = qw * s_w[k] + w_offset[k] (dlmcq_conv2d_i8_nhwc_asym)."""
+    `w_offset` ([K] fp32): asymmetric per-channel weights w' = qw * s_w[k] + w_offset[k] (dlmcq_conv2d_i8_nhwc_asym).
+    `force_tiled` (DLMCQ_FORCE_TILED): the generic tiled kernel even where the library's dispatch would pick a specialised one -
+    the same results bit for bit; tests compare the two on one tensor, tools time them on one box."""
     N.require_gpu(codes, wq)
     linear = codes.dim() == 2
     if linear:
@@ -452,20 +454,8 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
             n, h, w_, c, K, R, S, int(stride), int(padding), int(dilation), int(codes.dtype == torch.uint8))
     out_elems = n * K * P * Q
     ops = 2 * out_elems * c * R * S
-    # which kernel of the library takes the launch (conv3x3_halo_applies, csrc/conv3x3_i8.hip): the profile tag only
-    halo = (not linear and (R, S) == (3, 3) and stride in (1, 2) and padding == 1 and dilation == 1 and not want_out and emit is not None
-            and residual is None and w_offset is None and c % 64 == 0 and K % 64 == 0 and (stride == 1 or (h | w_) & 1 == 0)
-            and (stride == 1 or Q + 1 <= 62) and not (stride == 2 and c == 64 and K != 64) and Q + 1 <= 120)
-    # ... and conv_pw_applies (csrc/conv_pw_i8.hip: pointwise codes-to-codes layers, weights resident in LDS)
-    pw = (not linear and (R, S) == (1, 1) and stride == 1 and padding == 0 and dilation == 1 and not want_out and emit is not None
-          and residual is None and c in (64, 128, 192, 512, 1024) and (K in (64, 192) or K % 128 == 0) and K <= 1024 and n * h * w_ >= 4096
-          and n * h * w_ * max(c, K) < 0x7fff0000 and emit.zero_point is None and (emit.lo, emit.hi) == (0, 255))
-    # ... and conv_pwr_applies (csrc/conv_pwr_i8.hip: 1x1 block ends with an fp32 shortcut, ReLU and the consumer's plain codes)
-    pwr = (not linear and (R, S) == (1, 1) and stride == 1 and padding == 0 and dilation == 1 and residual is not None
-           and relu and w_offset is None and c in (256, 512) and K % 128 == 0 and K <= 4096 and n * h * w_ >= 4096 and (n * h * w_) % 32 == 0
-           and n * h * w_ * K * 4 < 0x7fff0000
-           and (want_out if emit is None else (emit.zero_point is None and (emit.lo, emit.hi) == (0, 255))))
-    tag = "conv3x3_halo" if halo else ("conv_pw" if pw else ("conv_pwr" if pwr else "conv_i8"))
+    # (the profile tag - which kernel of the library takes the launch - is asked of the library itself: the same call with
+    #  DLMCQ_ROUTE_ONLY runs the dispatch code and launches nothing; only when bench.py's per-kernel events are on)
     if fused:
         out_codes = q_scale = q_zp = None
         lo = hi = form = 0
@@ -484,21 +474,29 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
             q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, ref).reshape(-1)
             lo, hi, form, g = emit.lo, emit.hi, emit.form_arg, emit.g
         nbytes = codes.numel() + wq.numel() + out_elems * (4 * (out is not None) + 4 * (residual is not None) + (emit is not None))
+        form |= N.FORCE_TILED if force_tiled else 0
         if w_offset is not None:
-            PROFILE.launch(tag, nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_asym(
-                *args[:8], N.ptr(w_offset), *args[8:], N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp),
-                lo, hi, form, g, N.stream_ptr())), ops)
+            def call(extra=0):
+                return N.lib.dlmcq_conv2d_i8_nhwc_asym(
+                    *args[:8], N.ptr(w_offset), *args[8:], N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp),
+                    lo, hi, form | extra, g, N.stream_ptr())
         else:
-            PROFILE.launch(tag, nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_fused(
-                *args, N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g,
-                N.stream_ptr())), ops)
+            def call(extra=0):
+                return N.lib.dlmcq_conv2d_i8_nhwc_fused(
+                    *args, N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form | extra, g,
+                    N.stream_ptr())
+        tag = N.ROUTE_TAG[N.route(call(N.ROUTE_ONLY))] if PROFILE.enabled else "conv_i8"
+        PROFILE.launch(tag, nbytes, lambda: N.check(call()), ops)
         return (out, out_codes) if emit is not None else out
+    if force_tiled:
+        raise ValueError("conv2d_i8: force_tiled needs an epilogue (the plain fp32 entry point always runs the tiled kernel)")
     args = args + (N.stream_ptr(),)
-    PROFILE.launch(tag, codes.numel() + out_elems * 4 + wq.numel(), lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(*args)), ops)
+    PROFILE.launch("conv_i8", codes.numel() + out_elems * 4 + wq.numel(), lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_f32(*args)), ops)
     return out
 
 
-def conv2d_dw_i8(codes, wq, bias, in_scale, in_zp, w_scale, w_offset=None, stride=1, padding=0, relu=False, emit=None, want_out=True):
+def conv2d_dw_i8(codes, wq, bias, in_scale, in_zp, w_scale, w_offset=None, stride=1, padding=0, relu=False, emit=None, want_out=True,
+                 force_tiled=False):
     """Depthwise convolution on activation codes (dlmcq_conv2d_dw_i8_nhwc).  codes: (N, C, H, W) uint8/int8 channels_last,
     C % 4 == 0; wq: int8 [R, S, C] (tap-major); per-channel w_scale / w_offset / bias [C].  Returns fp32 (N, C, P, Q)
     channels_last, or `(out, codes)` with `emit`."""
@@ -529,15 +527,16 @@ def conv2d_dw_i8(codes, wq, bias, in_scale, in_zp, w_scale, w_offset=None, strid
         q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, codes).reshape(-1)
         lo, hi, form, g = emit.lo, emit.hi, emit.form, emit.g
     oe = n * c * P * Q
-    # which kernel of the library takes the launch (conv_dwm_applies, csrc/conv_dwm_i8.hip: 3x3 / 1 / 1 codes-only layers with the plain
-    # quantiser on the matrix cores): the profile tag only
-    dwm = ((R, S) == (3, 3) and stride == 1 and padding == 1 and not want_out and emit is not None and emit.zero_point is None and
-           (emit.lo, emit.hi) == (0, 255) and c % 64 == 0 and 14 <= w_ <= 62 and n * h * w_ >= 4096 and n * h * w_ * c < 0x7fff0000)
-    PROFILE.launch("conv_dwm" if dwm else "conv_dw", codes.numel() + wq.numel() + oe * (4 * want_out + (emit is not None)),
-                   lambda: N.check(N.lib.dlmcq_conv2d_dw_i8_nhwc(
-                       N.ptr(codes), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale), N.ptr(w_offset),
-                       n, h, w_, c, R, S, int(stride), int(padding), int(codes.dtype == torch.uint8), int(bool(relu)), N.ptr(out_codes),
-                       N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())), 2 * oe * R * S)
+    form |= N.FORCE_TILED if force_tiled else 0
+
+    def call(extra=0):
+        return N.lib.dlmcq_conv2d_dw_i8_nhwc(
+            N.ptr(codes), N.ptr(wq), N.ptr(out), N.ptr(bias), N.ptr(in_scale), N.ptr(in_zp), N.ptr(w_scale), N.ptr(w_offset),
+            n, h, w_, c, R, S, int(stride), int(padding), int(codes.dtype == torch.uint8), int(bool(relu)), N.ptr(out_codes),
+            N.ptr(q_scale), N.ptr(q_zp), lo, hi, form | extra, g, N.stream_ptr())
+    # (the profile tag - conv_dw: the vector kernels, conv_dwm: the matrix-core kernel - from the library's own dispatch, DLMCQ_ROUTE_ONLY)
+    tag = N.ROUTE_TAG[N.route(call(N.ROUTE_ONLY))] if PROFILE.enabled else "conv_dw"
+    PROFILE.launch(tag, codes.numel() + wq.numel() + oe * (4 * want_out + (emit is not None)), lambda: N.check(call()), 2 * oe * R * S)
     return (out, out_codes) if emit is not None else out
 
 
@@ -602,10 +601,10 @@ def conv2d_dwpw_i8(codes, table, dw_asym, dw_bias, dw_relu, in_zp, emit, pw, rel
     return out
 
 
-def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True):
+def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True, force_tiled=False):
     """conv(a) + conv(b) in one kernel (dlmcq_conv2d_i8_nhwc_dual).  `a`, `b`: dicts with codes, wq, wsum, bias,
     in_scale, in_zp, w_scale and optional stride / padding / dilation; both must produce the same output shape.
-    Returns fp32 (N, K, P, Q) channels_last, or `(out, codes)` with `emit` (see conv2d_i8)."""
+    Returns fp32 (N, K, P, Q) channels_last, or `(out, codes)` with `emit` (see conv2d_i8; `force_tiled` as there)."""
     def prep(t):
         c = t["codes"]
         N.require_gpu(c, t["wq"])
@@ -648,18 +647,17 @@ def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True):
     def touched(c, r, s_, stride):     # a strided 1x1 convolution reads only the pixels it samples
         return c.numel() // (stride * stride) if r == 1 and s_ == 1 else c.numel()
     nbytes = touched(ca, R, S, st) + touched(cb, R2, S2, st2) + a["wq"].numel() + b["wq"].numel() + oe * (4 * want_out + (emit is not None))
-    # which kernel of the library takes the launch (conv_pwr_applies, csrc/conv_pwr_i8.hip: the dual form with both weight slices in LDS)
-    pwr = (relu and want_out and emit is not None and emit.zero_point is None and (emit.lo, emit.hi) == (0, 255)
-           and (R, S, pd, dl, R2, S2, pd2, dl2) == (1, 1, 0, 1, 1, 1, 0, 1) and K_ % 128 == 0 and K_ <= 4096
-           and ((st == 1 and ch == 256 and ch2 == 512) or (st2 == 1 and ch2 == 256 and ch == 512))
-           and n * P * Q >= 4096 and (n * P * Q) % 32 == 0 and n * P * Q * K_ * 4 < 0x7fff0000
-           and (cb.numel() if ch2 == 512 else ca.numel()) < 0x7fff0000)
-    PROFILE.launch("conv_pwr" if pwr else "conv_i8", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_dual(
-        N.ptr(ca), N.ptr(a["wq"]), N.ptr(out), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa),
-        n, h, w_, ch, K_, R, S, st, pd, dl, uns,
-        N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2, ch2, R2, S2, st2, pd2, dl2,
-        uns2, int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form, g, N.stream_ptr())),
-        2 * oe * (ch * R * S + ch2 * R2 * S2))
+    form |= N.FORCE_TILED if force_tiled else 0
+
+    def call(extra=0):
+        return N.lib.dlmcq_conv2d_i8_nhwc_dual(
+            N.ptr(ca), N.ptr(a["wq"]), N.ptr(out), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa),
+            n, h, w_, ch, K_, R, S, st, pd, dl, uns,
+            N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2, ch2, R2, S2, st2, pd2, dl2,
+            uns2, int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form | extra, g, N.stream_ptr())
+    # (the profile tag from the library's own dispatch: conv_pwr = csrc/conv_pwr_i8.hip's dual form, conv_i8 = the tiled dual kernel)
+    tag = N.ROUTE_TAG[N.route(call(N.ROUTE_ONLY))] if PROFILE.enabled else "conv_i8"
+    PROFILE.launch(tag, nbytes, lambda: N.check(call()), 2 * oe * (ch * R * S + ch2 * R2 * S2))
     return (out, out_codes) if emit is not None else out
 
 

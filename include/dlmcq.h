@@ -79,6 +79,22 @@ typedef void* dlmcq_stream_t; /* hipStream_t */
  * (element [n][k2][j] = KRSC element [k2][64 n + j]), so that the 64-column chunk the kernel stages per step is one contiguous
  * K2 x 64 byte block (whole cache lines per LDS-DMA instruction instead of 64-byte pieces of K-byte rows).  Same results. */
 #define DLMCQ_W2_CHUNK_MAJOR 0x200
+/* Two control bits, OR-able into the `q_form` argument of dlmcq_conv2d_i8_nhwc_fused / _asym / _dual and dlmcq_conv2d_dw_i8_nhwc.
+ * DLMCQ_FORCE_TILED: the call runs on the generic kernel of its family (conv_i8_mfma_kernel; conv_dw3*_i8_kernel for the
+ * depthwise entry point) even where the library's dispatch would hand it to a specialised one (halo-tile 3x3, weight-resident
+ * pointwise, block-end pointwise, matrix-core depthwise).  Same results bit for bit; it exists so that a specialised kernel and
+ * the kernel it replaces can be compared on ONE tensor at any size (tests/, tools/) and for same-box A/B timing.
+ * DLMCQ_ROUTE_ONLY: nothing is launched; the call validates its arguments exactly as the real call does and returns WHICH kernel
+ * the dispatch picks for them (DLMCQ_ROUTE_*, all > 0; errors stay negative) - the dispatch code itself answers, so a caller's
+ * bookkeeping (bench.py's per-kernel-family rooflines) cannot drift from what runs. */
+#define DLMCQ_FORCE_TILED 0x400
+#define DLMCQ_ROUTE_ONLY 0x800
+#define DLMCQ_ROUTE_TILED 1   /* conv_i8_mfma_kernel (csrc/conv_i8.hip) */
+#define DLMCQ_ROUTE_HALO3X3 2 /* conv3x3_halo_i8_kernel (csrc/conv3x3_i8.hip) */
+#define DLMCQ_ROUTE_PW 3      /* conv_pw_i8_kernel (csrc/conv_pw_i8.hip) */
+#define DLMCQ_ROUTE_PWR 4     /* conv_pwr_i8_kernel (csrc/conv_pwr_i8.hip) */
+#define DLMCQ_ROUTE_DW 5      /* conv_dw_i8_kernel / conv_dw3_i8_kernel / conv_dw3p2_i8_kernel (csrc/conv_dw_i8.hip) */
+#define DLMCQ_ROUTE_DWM 6     /* conv_dwm_i8_kernel (csrc/conv_dwm_i8.hip) */
 
 /* ---- what is written to `y` ---- */
 #define DLMCQ_Y_DEQUANT 0 /* the fake-quantised value y */

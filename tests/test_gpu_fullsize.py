@@ -33,11 +33,23 @@ FSPTQ = {  # example/quantization/FSPTQ_config.yaml:40-53
 
 
 def _windows(n_img, P, Q, size=6):
-    """(image, p0, q0, ph, qw): both corners of the first / a middle / the last image (the end of the tensor)."""
+    """(image, p0, q0, ph, qw): both corners of the first / a middle / the last image (the end of the tensor), and - round 5 - windows
+    that STRADDLE TILE SEAMS: the kernels cut the pixel index m = (n P + p) Q + q into blocks of 32 (pointwise), 64 (chain), 128 (tiled)
+    and 256 rows (halo, in frame positions), so in two interior images a window is laid around the first pixel whose index is a multiple
+    of 256 (a seam of every one of those block sizes at once: pixels m - 1 and m sit in different tiles), and the first corner of image 1
+    faces the last corner of image 0 (an image boundary inside a tile)."""
     ph, qw = min(size, P), min(size, Q)
     out = []
     for n in sorted({0, n_img // 2, n_img - 1}):
         out += [(n, 0, 0, ph, qw), (n, P - ph, Q - qw, ph, qw)]
+    if n_img > 2:
+        out.append((1, 0, 0, ph, qw))
+    for n in sorted({n_img // 3, (2 * n_img) // 3}):
+        m0 = n * P * Q
+        seam = -(-m0 // 256) * 256 - m0            # first pixel of this image whose index is a multiple of 256
+        if 0 < seam < P * Q:
+            p, q = seam // Q, seam % Q
+            out.append((n, max(0, min(P - ph, p - ph // 2)), max(0, min(Q - qw, q - qw // 2)), ph, qw))
     return out
 
 

@@ -69,7 +69,11 @@ def test_mobileone_s1_w4a8_plan_node_by_node(family, batch, size, full):
     assert worst <= 1.2e-4, rates            # twice what round 3 measured (5.9e-5 at batch 1024): a drift must not hide under the 2e-3 bound
     # logits against the module path: same codes layer by layer up to fp32 accumulation-order ties
     spread = float(want.std())
-    assert float((got - want).abs().mean()) < 0.05 * spread and torch.equal(got.argmax(1), want.argmax(1)) or batch > 8
+    # (round 5: `A and B or batch > 8` had skipped BOTH checks above batch 8.  The mean deviation is checked at every batch; the predicted
+    #  class must agree on every image of a small batch and on all but a tie-breaking handful of a large one)
+    assert float((got - want).abs().mean()) < 0.05 * spread, (float((got - want).abs().mean()), spread)
+    agree = float((got.argmax(1) == want.argmax(1)).double().mean())
+    assert agree == 1.0 if batch <= 8 else agree >= 0.98, agree
 
 
 def test_depthwise_kernel_shapes_and_forms():
@@ -173,6 +177,12 @@ def test_depthwise_on_the_matrix_cores_is_the_vector_kernel_bit_for_bit(n, c, h,
     assert [r[0] for r in K.PROFILE.records] == ["conv_dwm", "conv_dw"]      # (the profile tag follows the library's own dispatch rule)
     K.PROFILE.reset()
     assert torch.equal(got[:1], first)
+    # round 5: the whole tensor through the vector kernel (DLMCQ_FORCE_TILED on the depthwise entry point)
+    none, whole = K.conv2d_dw_i8(cd, wq, None if bias is None else bias.to(DEV), torch.tensor([s_in], device=DEV), torch.tensor([zp], device=DEV),
+                                 s_w.to(DEV), None if o_w is None else o_w.to(DEV), stride=1, padding=1, relu=True, emit=emit, want_out=False,
+                                 force_tiled=True)
+    assert torch.equal(got, whole), f"{int((got != whole).sum())} of {got.numel()} codes differ from the vector kernel"
+    del whole
     nsub = max(1, 4095 // (h * w))
     for i0 in (0, n - nsub):            # the first and the last images through the vector kernel
         sub = run(cd[i0:i0 + nsub].contiguous(memory_format=torch.channels_last))

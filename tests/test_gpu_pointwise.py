@@ -74,14 +74,20 @@ def test_pointwise_kernel_is_the_tiled_kernel_bit_for_bit(case):
     q_scale = torch.full((1,), 0.043, device=DEV)
     emit = K.EmitCodes(q_scale, None, 0, 255, N.FORM_ZEROPOINT)
 
-    def run(cd):
-        _, got = K.conv2d_i8(cd, wq, wsum, bias, s_in, in_zp, s_w, relu=relu, emit=emit, want_out=False, w_offset=w_off)
+    def run(cd, force_tiled=False):
+        _, got = K.conv2d_i8(cd, wq, wsum, bias, s_in, in_zp, s_w, relu=relu, emit=emit, want_out=False, w_offset=w_off, force_tiled=force_tiled)
         return got
     m = n * h * w
     assert m >= 4096
     got, tags = _tagged(K, lambda: run(codes))
-    assert tags == ["conv_pw"], tags           # (the tag follows the library's own dispatch rule)
+    assert tags == ["conv_pw"], tags           # (the tag is the library's own answer: the call again with DLMCQ_ROUTE_ONLY)
     torch.cuda.synchronize()
+    # round 5: the WHOLE tensor through the tiled kernel (DLMCQ_FORCE_TILED) - every block of every workgroup faces the kernel it replaces,
+    # at the stated sizes too (1 024 x 28^2 x 192, 1 024 x 14^2 x 512), not only the first and last sub-batch
+    whole, tags = _tagged(K, lambda: run(codes, force_tiled=True))
+    assert tags == ["conv_i8"], tags
+    assert torch.equal(got, whole), f"pointwise kernel differs from the tiled kernel on {int((got != whole).sum())} of {got.numel()} codes"
+    del whole
     # the tiled kernel: the same layer on the first images only (fewer than 4 096 pixels: conv_pw_applies declines)
     nsub = max(1, 4095 // (h * w))
     sub, tags = _tagged(K, lambda: run(codes[:nsub].contiguous(memory_format=torch.channels_last)))
@@ -120,6 +126,32 @@ def test_pointwise_kernel_emits_recentred_codes_like_the_tiled_kernel():
     assert shifted.dtype == torch.int8 and torch.equal(shifted.to(torch.int16) + 128, plain.to(torch.int16))
     sub = run(codes[:9].contiguous(memory_format=torch.channels_last), True)          # 3 600 pixels: the tiled kernel
     assert torch.equal(shifted[:9], sub)
+
+
+@pytest.mark.parametrize("c,k", [(128, 64), (192, 64), (512, 64), (1024, 64), (512, 192), (1024, 192)], ids=str)
+def test_pointwise_pairs_without_an_instantiation_take_the_tiled_kernel(c, k):
+    """conv_pw_applies admitted (C, K) pairs conv_pw_launch has no instantiation for - a codes-to-codes 1x1 layer such as
+    128 -> 64 or 512 -> 192 with the plain quantiser and >= 4 096 pixels then failed with DLMCQ_EINVAL instead of running on the tiled kernel.
+    The predicate and the launch table are one list now: these pairs route to the tiled kernel and give the float64 reference's codes."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator(device=DEV).manual_seed(c + k)
+    n, h, w = 6, 28, 28                                   # 4 704 pixels
+    codes = torch.randint(0, 256, (n, c, h, w), generator=g, device=DEV, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+    wq = torch.randint(-127, 128, (k, 1, 1, c), generator=g, device=DEV, dtype=torch.int8)
+    wsum = wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
+    s_w = (torch.rand(k, generator=g, device=DEV) * 0.0004 + 0.00005).contiguous()
+    bias = torch.randn(k, generator=g, device=DEV).contiguous()
+    s_in, q_scale = torch.full((1,), 0.021, device=DEV), torch.full((1,), 0.043, device=DEV)
+    emit = K.EmitCodes(q_scale, None, 0, 255, N.FORM_ZEROPOINT)
+    (_, got), tags = _tagged(K, lambda: K.conv2d_i8(codes, wq, wsum, bias, s_in, None, s_w, relu=True, emit=emit, want_out=False))
+    assert tags == ["conv_i8"], tags
+    (_, forced), _ = _tagged(K, lambda: K.conv2d_i8(codes, wq, wsum, bias, s_in, None, s_w, relu=True, emit=emit, want_out=False, force_tiled=True))
+    assert torch.equal(got, forced)
+    m = n * h * w
+    want = _reference_codes(codes.permute(0, 2, 3, 1).reshape(m, c), 0.0, s_in, wq.reshape(k, c), s_w, None, bias, True, q_scale, 255)
+    diff = (got.permute(0, 2, 3, 1).reshape(m, k).double() - want).abs()
+    assert float(diff.max()) <= 1.0 and float((diff > 0).double().mean()) < 1e-3
 
 
 def test_pointwise_kernel_leaves_the_rest_to_the_tiled_kernel():
@@ -184,6 +216,14 @@ def test_residual_block_end_kernel_is_the_tiled_kernel_bit_for_bit(case):
     (out, got), tags = _tagged(K, lambda: run(codes, short))
     assert tags == ["conv_pwr"], tags
     torch.cuda.synchronize()
+    # round 5: the whole tensor through the tiled kernel (DLMCQ_FORCE_TILED): codes and fp32 bits, every pixel block of every slice
+    (ow, gw), tags = _tagged(K, lambda: K.conv2d_i8(codes, wq, wsum, bias, s_in, in_zp, s_w, residual=short, relu=True, emit=emit, want_out=want_out,
+                                                  force_tiled=True))
+    assert tags == ["conv_i8"], tags
+    assert torch.equal(got, gw), f"{int((got != gw).sum())} of {got.numel()} codes differ from the tiled kernel"
+    if want_out:
+        assert torch.equal(out.view(torch.int32), ow.view(torch.int32)), "fp32 block output differs from the tiled kernel (bitwise, whole tensor)"
+    del ow, gw
     nsub = max(1, 4095 // (h * w))
     cl = lambda t: t.contiguous(memory_format=torch.channels_last)
     for sl in (slice(0, nsub), slice(n - nsub, n)):        # the tiled kernel on the first and on the last images (fewer than 4 096 pixels)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Clock stamps of every workgroup of the chain kernel (lab library): start, A fragments loaded, per chunk {operands there,
-GEMM 1 + epilogue 1 issued, past the mid-chunk barrier}, chunks done, end.   python tools/chain_trace.py N C H K K2"""
+GEMM 1 + epilogue 1 issued, past the mid-chunk barrier}, chunks done, end.   python tools/chain_trace.py N C H K K2 [plain] [lab=F] [noout]
+(plain: the plan's launch form - null zero points, chunk-major second weights; lab=F: a timing-only ablation of the lab library, e.g. 1 = no
+shortcut loads; noout: no fp32 stores)"""
 import ctypes
 import os
 import sys
@@ -15,6 +17,11 @@ from dlmc import _native as N  # noqa: E402
 from dlmc.quantization.scalar import kernels as K  # noqa: E402
 
 n, c, h, k, k2 = [int(v) for v in sys.argv[1:6]]
+opts = sys.argv[6:]
+plain, noout = "plain" in opts, "noout" in opts
+labf = max([int(o[4:]) for o in opts if o.startswith("lab=")] + [0])
+c2 = max([int(o[3:]) for o in opts if o.startswith("c2=")] + [0])        # dual form: the shortcut is a 1x1 convolution of c2 channels ...
+st2 = max([int(o[4:]) for o in opts if o.startswith("st2=")] + [1])      # ... sampled at this stride from an (h * st2)^2 image
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(1)
 x = torch.randint(0, 256, (n, c, h, h), generator=g, device=dev, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
@@ -25,17 +32,32 @@ a = dict(codes=x, wq=w1, wsum=w1.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int
 b = dict(wq=w2, wsum=w2.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous(), bias=torch.randn(k2, device=dev),
          w_scale=torch.full((k2,), 0.001, device=dev))
 res = torch.randn(n, k, h, h, generator=g, device=dev).contiguous(memory_format=torch.channels_last)
-emit = K.EmitCodes(torch.full((1,), 0.05, device=dev), torch.zeros(1, device=dev), 0, 255, N.FORM_ZEROPOINT)
-emit2 = K.EmitCodes(torch.full((1,), 0.11, device=dev), torch.zeros(1, device=dev), 0, 255, N.FORM_ZEROPOINT)
+zp = None if plain else torch.zeros(1, device=dev)
+emit = K.EmitCodes(torch.full((1,), 0.05, device=dev), zp, 0, 255, N.FORM_ZEROPOINT)
+emit2 = K.EmitCodes(torch.full((1,), 0.11, device=dev), zp, 0, 255, N.FORM_ZEROPOINT)
+if plain:
+    a["in_zp"] = None
+    b["wq_chunk"] = K.chunk_major(b["wq"])
 m = n * h * h
 nwg = (m + 63) // 64
 trace = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
 N.lib.dlmcq_x_chain_trace.restype = None
 N.lib.dlmcq_x_chain_trace.argtypes = [ctypes.c_void_p]
 N.lib.dlmcq_x_chain_trace(N.ptr(trace))
+N.lib.dlmcq_x_chain_lab(labf)
+if c2:
+    x2 = torch.randint(0, 256, (n, c2, h * st2, h * st2), generator=g, device=dev, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+    w_s = torch.randint(-127, 128, (k, 1, 1, c2), generator=g, device=dev, dtype=torch.int8)
+    sc = dict(codes=x2, wq=w_s, wsum=w_s.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous(), bias=torch.randn(k, device=dev),
+              in_scale=torch.full((1,), 0.03, device=dev), in_zp=zp, w_scale=torch.full((k,), 0.001, device=dev), stride=st2)
 for _ in range(2):
-    K.conv2d_i8_chain(a, b, res, emit=emit, want_out=True, emit2=emit2, rows_per_tile=64)
+    if c2:
+        K.conv2d_i8_dual_chain(a, sc, b, emit=emit, want_out=not noout, emit3=emit2, rows_per_tile=64)
+    else:
+        K.conv2d_i8_chain(a, b, res, emit=emit, want_out=not noout, emit2=emit2, rows_per_tile=64)
 torch.cuda.synchronize()
+N.lib.dlmcq_x_chain_lab(0)
+print(f"# {' '.join(sys.argv[1:])}")
 t = trace.cpu().reshape(nwg, 64)
 nc = k // 64
 nst = 2 + 3 * nc + 2

@@ -14,12 +14,24 @@ if [ "$PART" = all ] || [ "$PART" = 1 ]; then
 python3 "$B" --steps 20 --warmup 5 > "$OUT/bench_line.json" 2> "$OUT/bench.err"
 python3 "$B" --steps 20 --warmup 5 --streams 1 --no-cpu-baseline > "$OUT/bench_line_streams1.json" 2>> "$OUT/bench.err"
 # per-kernel durations of the same command (one stream: rocprofv3 and the HIP events then describe the same thing)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python3 "$B" --steps 20 --warmup 5 --streams 1 --no-cpu-baseline > "$OUT/stats.log" 2>&1 || echo "stats pass failed"
-# HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/fetch.log" 2>&1 || echo "fetch pass failed"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/write.log" 2>&1 || echo "write pass failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python3 "$B" --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-other-configs --no-fake-quant-leg > "$OUT/stats.log" 2>&1 || echo "stats pass failed"
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section).  --no-other-configs / --no-fake-quant-leg:
+# `pmc_summary.py --tail KERNEL N` takes the LAST N dispatches of a kernel in the process, so nothing but the headline network may run in
+# these passes (round 4's passes also ran RepVGG-A1 and MobileOne-S1 behind it: two families' tails were the side networks' launches)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-other-configs --no-fake-quant-leg > "$OUT/fetch.log" 2>&1 || echo "fetch pass failed"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-other-configs --no-fake-quant-leg > "$OUT/write.log" 2>&1 || echo "write pass failed"
 cd "$GRAFT_REPO_ROOT"
 python3 tools/pmc_summary.py --tail conv_chain_i8_kernel 11 --tail conv_i8_mfma_kernel 6 --tail conv3x3_halo_i8_kernel 16 --tail conv_pwr_i8_kernel 4 --tail conv_stem_pool7_i8_kernel 1 --tail quantize_pad_nhwc4 1 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
+# the side networks' own passes (their rooflines' traffic): RepVGG-A1's 21 halo-kernel layers, MobileOne-S1's depthwise / pointwise families
+cd /tmp
+for mk in "repvgg_a1 conv3x3_halo_i8_kernel:21" "mobileone_s1 conv_dwm_i8_kernel:17,conv_pw_i8_kernel:21"; do
+  set -- $mk; M=$1; TAILS=""
+  for kv in $(echo $2 | tr ',' ' '); do TAILS="$TAILS --tail ${kv%%:*} ${kv##*:}"; done
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_$M" -o p -- python3 "$B" --model $M --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/fetch_$M.log" 2>&1 || echo "fetch pass $M failed"
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write_$M" -o p -- python3 "$B" --model $M --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/write_$M.log" 2>&1 || echo "write pass $M failed"
+  (cd "$GRAFT_REPO_ROOT" && python3 tools/pmc_summary.py $TAILS "$OUT/fetch_$M" "$OUT/write_$M" > "$OUT/pmc_bench_$M.json") || true
+done
+cd "$GRAFT_REPO_ROOT"
 python3 tools/plan_profile.py resnet50 512 > "$OUT/plan_profile_resnet50_b512.txt" 2>&1
 python3 tools/plan_profile.py repvgg_a1 512 > "$OUT/plan_profile_repvgg_a1_b512.txt" 2>&1
 python3 tools/plan_profile.py mobileone_s1 1024 > "$OUT/plan_profile_mobileone_s1_b1024.txt" 2>&1

@@ -73,9 +73,28 @@ def in_flight_check(name, body):
             else:
                 print(f"{name}: no vmcnt wait found behind the load at line {i}")
                 bad += 1
+    # round 5: chunk 0's shortcut tile is requested in the PROLOGUE, before the wave waits for its input tile (a counted wait that leaves
+    # these loads in flight): from each such load to the first `s_waitcnt vmcnt(0)` in listing order nothing may touch its registers
+    first_head = min(heads)
+    pro = [(i, m) for i, m in loads if i < first_head and m]
+    for i, m in pro:
+        mine = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        for j in range(i + 1, len(body)):
+            line = body[j]
+            if "s_waitcnt" in line and "vmcnt(0)" in line:
+                break
+            if "buffer_load_dwordx4" not in line:
+                hit = regs(line) & mine
+                if hit:
+                    print(f"{name}: line {j}: `{line.strip()}` touches registers {sorted(hit)} of the prologue load at line {i} still in flight")
+                    bad += 1
+    checked_pro = len(pro)
     fp32_shortcut = re.search(r"kernelILi\d+ELi\d+ELi0E", name) is not None     # (C2 = 0; the others reduce a convolution shortcut instead)
     if fp32_shortcut and checked < 4:   # at least one 4-load shortcut tile request inside the chunk loop: a vacuous pass is a failure
         print(f"{name}: only {checked} in-loop asm loads found - the check did not see the chunk loop")
+        bad += 1
+    if fp32_shortcut and checked_pro < 4:
+        print(f"{name}: only {checked_pro} prologue asm loads found - the check did not see chunk 0's request")
         bad += 1
     return bad
 
