@@ -70,8 +70,15 @@ __device__ __forceinline__ v4i make_rsrc(const void* p, uint32_t bytes) {
   const uint64_t a = (uint64_t)p;
   return v4i{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
+// The fp32 streams (shortcut in, block output out) carry the non-temporal hint: measured twice (LABNOTES 13, 14) against temporal
+// accesses - whole batches and cache-sized sub-batches walked through a stage.  -DDLMCQ_FP32_TEMPORAL builds the A/B library without it.
+#ifdef DLMCQ_FP32_TEMPORAL
+#define DLMCQ_NT ""
+#else
+#define DLMCQ_NT " nt"
+#endif
 __device__ __forceinline__ void bload16(f32x4& dst, int voff, const v4i& rsrc) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" DLMCQ_NT : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void bload16i(i32x4& dst, int voff, const v4i& rsrc) {
@@ -81,7 +88,7 @@ __device__ __forceinline__ void bload16i(i32x4& dst, int voff, const v4i& rsrc) 
 //  overwrite them, and the hazard recogniser does not see inside inline asm - with one, the last quad of every 16 lanes
 //  can store the NEXT value of a dword)
 __device__ __forceinline__ void bstore16(const f32x4& v, int voff, const v4i& rsrc) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" DLMCQ_NT "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void bstore16i(const i32x4& v, int voff, const v4i& rsrc) {
   asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");

@@ -55,10 +55,10 @@ constexpr int PWR_BN = 128;
 constexpr int PWR_FROW = 36;    // floats per row of the fp32 stage (32 + 4: conflict-free 16-byte writes from the accumulator layout)
 
 __device__ __forceinline__ void bload16s(f32x4& dst, int voff, const v4i& rsrc, int soff) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" DLMCQ_NT : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void bstore16s(const f32x4& v, int voff, const v4i& rsrc, int soff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" DLMCQ_NT "\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
 // CODES: the consumer's codes are emitted (false: the fp32 output alone - a network's last block)
