@@ -942,9 +942,10 @@ def fake_quant_backward(x, gy, scale, offset, lo, hi, g, ch_axis=None, want_gx=T
     gs = torch.empty(ch, dtype=torch.float32, device=x.device) if want_gscale else None
     nb = N.lib.dlmcq_fq_bwd_scratch_bytes(outer, ch, inner)
     sc = _scratch(nb, x.device)
-    N.check(N.lib.dlmcq_fake_quant_bwd_form_f32(N.ptr(x), N.ptr(gy), N.ptr(gx), N.ptr(gs), N.ptr(scale), N.ptr(offset), outer,
-                                                ch, inner, int(lo), int(hi), int(N.FORM_QBASE if form is None else form), float(g),
-                                                N.ptr(sc), sc.numel() * 4, N.stream_ptr()))
+    # algorithmic bytes: x and gy read, gx written (12 per element; 8 when only the scale gradient is wanted)
+    PROFILE.launch("fq_bwd", x.numel() * (8 + 4 * bool(want_gx)), lambda: N.check(N.lib.dlmcq_fake_quant_bwd_form_f32(
+        N.ptr(x), N.ptr(gy), N.ptr(gx), N.ptr(gs), N.ptr(scale), N.ptr(offset), outer, ch, inner, int(lo), int(hi),
+        int(N.FORM_QBASE if form is None else form), float(g), N.ptr(sc), sc.numel() * 4, N.stream_ptr())))
     return gx, gs
 
 

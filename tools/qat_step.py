@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
 """Training-step time (forward + backward + SGD) of the three wrapper families - the reference's QAT use of the path
-(trainer/quantization_aware_training_trainer.py:50-80).  python tools/qat_step.py [model] [batch]"""
+(trainer/quantization_aware_training_trainer.py:51-75: output = model(data); loss.backward(); optimizer.step()).
+
+    python tools/qat_step.py [model] [batch] [--json FILE]
+
+Prints ms per step and images/s per family and - round 5 - the fake-quant kernels' own rates inside one more, instrumented step
+(HIP events per launch: forward fq_tensor / fq_channel at 8 algorithmic bytes per element, the one-pass backward `fq_bwd` at 12);
+--json writes the whole record (profiles/r05_qat_step_<model>.json)."""
 import json
 import os
 import sys
@@ -13,8 +19,15 @@ import torch  # noqa: E402
 import workloads as W  # noqa: E402
 from dlmc.utils.quantize import quantize_model  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else "resnet18"
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+argv = [a for a in sys.argv[1:]]
+json_path = None
+if "--json" in argv:
+    i = argv.index("--json")
+    json_path = argv[i + 1]
+    del argv[i:i + 2]
+name = argv[0] if len(argv) > 0 else "resnet18"
+batch = int(argv[1]) if len(argv) > 1 else 128
+from dlmc.quantization.scalar import kernels as K  # noqa: E402
 dev = "cuda:0"
 out = {}
 for family, wtype, asigned in (("QBase (LSQ-style)", "minmax_tensor", True), ("RootQ", "minmax_tensor", False), ("FSPTQ", "minmax_channel", False),
@@ -41,5 +54,29 @@ for family, wtype, asigned in (("QBase (LSQ-style)", "minmax_tensor", True), ("R
     for _ in range(10):
         step()
     torch.cuda.synchronize()
-    out[family] = round((time.perf_counter() - t0) / 10 * 1e3, 2)
-    print(f"{name} b{batch} {family:24s} {out[family]:8.2f} ms/step  {batch / out[family] * 1e3:8.0f} images/s", flush=True)
+    ms = round((time.perf_counter() - t0) / 10 * 1e3, 2)
+    rec = {"ms_per_step": ms, "images_per_s": round(batch / ms * 1e3, 1)}
+    if wtype is not None:       # one more step with HIP events on every launch of this project's kernels
+        K.PROFILE.reset()
+        K.PROFILE.enabled = True
+        step()
+        torch.cuda.synchronize()
+        K.PROFILE.enabled = False
+        fam = {}
+        for tag, nbytes, e0, e1, _ in K.PROFILE.records:
+            f = fam.setdefault(tag, {"launches": 0, "bytes": 0, "ms": 0.0})
+            f["launches"] += 1
+            f["bytes"] += nbytes
+            f["ms"] += e0.elapsed_time(e1)
+        K.PROFILE.reset()
+        rec["kernels"] = {k: {"launches": f["launches"], "ms": round(f["ms"], 3), "GBps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1),
+                              "frac_of_8TBps": round(f["bytes"] / (f["ms"] * 1e-3) / 8e12, 4)} for k, f in fam.items() if f["ms"] > 0}
+        rec["kernels_ms_total"] = round(sum(f["ms"] for f in fam.values()), 3)
+    out[family] = rec
+    extra = "  ".join(f"{k} {v['GBps']:.0f} GB/s x{v['launches']}" for k, v in rec.get("kernels", {}).items())
+    print(f"{name} b{batch} {family:24s} {ms:8.2f} ms/step  {batch / ms * 1e3:8.0f} images/s   {extra}", flush=True)
+if json_path:
+    with open(json_path, "w") as fh:
+        json.dump({"what": "QAT training step (forward + backward + SGD), W4A4, synthetic 224^2 batch; reference loop: "
+                           "trainer/quantization_aware_training_trainer.py:51-75", "model": name, "batch": batch,
+                   "device": torch.cuda.get_device_name(0), "families": out}, fh, indent=1)
