@@ -25,14 +25,14 @@ struct ConvEpi {
   int q_form;
   int relu;
   uint32_t q_xor;          // 0x80808080 when the codes are stored as int8 `code - 128` (DLMCQ_EMIT_SHIFT128), else 0
-  uint32_t ctl;            // host side only: DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY as passed in `q_form`
+  uint32_t ctl;            // host side only: DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY | DLMCQ_PIPELINED as passed in `q_form`
 };
 
 // `q_form` argument of an entry point -> (form, shifted-emission flag); false = invalid
 static inline bool epi_set_form(ConvEpi& ep, int32_t q_form, int32_t q_lo, int32_t q_hi) {
   const bool shifted = (q_form & DLMCQ_EMIT_SHIFT128) != 0;
-  ep.ctl = (uint32_t)q_form & (DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY);
-  ep.q_form = q_form & ~(DLMCQ_EMIT_SHIFT128 | DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY);
+  ep.ctl = (uint32_t)q_form & (DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY | DLMCQ_PIPELINED);
+  ep.q_form = q_form & ~(DLMCQ_EMIT_SHIFT128 | DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY | DLMCQ_PIPELINED);
   ep.q_xor = shifted ? 0x80808080u : 0u;
   return ep.q_form >= DLMCQ_FORM_EMULATE && ep.q_form <= DLMCQ_FORM_SYMMETRIC && (!shifted || (q_lo >= 0 && q_hi <= 255));
 }
@@ -235,6 +235,21 @@ struct EpiQuant {   // the consumer's constants, resolved once per thread
       for (int i = 0; i < N; ++i)
         if (bal[i]) w[i] = exact4(v[i], w[i]);
     }
+  }
+  // One quad of a PLAIN quantiser in two parts, for a caller that puts other work (matrix instructions) between the branch-free fast path and
+  // the rare redo: `w = code4_plain_fast(v, bal); ...; if (bal) w = exact4(v, w);` - code4n_plain<1> cut at its branch (csrc/conv3x3_pipe_i8.hip)
+  __device__ __forceinline__ uint32_t code4_plain_fast(const f32x4& v, uint64_t& bal) const {
+    const f32x2 rdv2 = f32x2{rdv, rdv};
+    const float thr = tie_thr;
+    const f32x2 ta = f32x2{v.x, v.y} * rdv2, tb = f32x2{v.z, v.w} * rdv2;
+    const f32x2 ra = f32x2{__builtin_rintf(ta.x), __builtin_rintf(ta.y)}, rb = f32x2{__builtin_rintf(tb.x), __builtin_rintf(tb.y)};
+    const f32x2 da = ta - ra, db = tb - rb;
+    bal = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(da.x) < thr)) | __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(da.y) < thr)) |
+          __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(db.x) < thr)) | __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(db.y) < thr));
+    uint32_t c = __builtin_amdgcn_cvt_pk_u8_f32(ra.x, 0, 0u);
+    c = __builtin_amdgcn_cvt_pk_u8_f32(ra.y, 1, c);
+    c = __builtin_amdgcn_cvt_pk_u8_f32(rb.x, 2, c);
+    return __builtin_amdgcn_cvt_pk_u8_f32(rb.y, 3, c) ^ xemit;
   }
   template <int N, bool PLAIN = false>
   __device__ __forceinline__ bool code4n(const f32x4 (&v)[N], uint32_t (&w)[N], bool (&u)[N]) const {

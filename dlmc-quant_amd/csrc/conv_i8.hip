@@ -699,9 +699,14 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   if (special && conv_pwr_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2))
     return route_only ? DLMCQ_ROUTE_PWR
                       : conv_pwr_launch(xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st, seg2);
-  if (special && conv3x3_halo_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
+  if (special && conv3x3_halo_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr)) {
+    // ... persistent and pipelined across tiles on request (DLMCQ_PIPELINED: csrc/conv3x3_pipe_i8.hip - bit-identical, measured slower)
+    if ((ep.ctl & DLMCQ_PIPELINED) && conv3x3_pipe_applies(N, H, W, C, K, stride, ep, device_cus()))
+      return route_only ? DLMCQ_ROUTE_HALO3X3_PIPE
+                        : conv3x3_pipe_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, shift, ep, st, device_cus());
     return route_only ? DLMCQ_ROUTE_HALO3X3
                       : conv3x3_halo_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, stride, shift, ep, st);
+  }
   // 256-wide tiles exist for the swapped codes-only layers only (one third fewer operand bytes per MAC, two workgroups per CU)
   const bool swap_ok = plan.swap && ep.codes && !out && !ep.residual && K % plan.bn == 0 && aligned16(ep.codes);
   // (192-wide tiles: the swapped asymmetric codes-only instantiation is the only one - a forced plan that asks for them anywhere

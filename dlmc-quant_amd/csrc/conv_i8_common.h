@@ -105,6 +105,23 @@ int conv3x3_halo_launch(const int8_t* x, const int8_t* w, const float* bias, con
                         const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K,
                         int32_t stride, int shift, const ConvEpi& ep, hipStream_t st, int lab = 0, void* lab_trace = nullptr);
 
+// conv3x3_pipe_i8.hip: the halo-tile kernel persistent and software-pipelined across tiles (stride 1, 128 / 256 / 512 input channels, plain quantiser)
+bool conv3x3_pipe_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int32_t stride, const ConvEpi& ep, int cus);
+int conv3x3_pipe_launch(const int8_t* x, const int8_t* w, const float* bias, const int32_t* wsum, const float* in_scale,
+                        const float* in_zero_point, const float* w_scale, int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int shift,
+                        const ConvEpi& ep, hipStream_t st, int cus);
+// compute units of the current device (cached: one device per process, dlmc/_native.py)
+inline int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
 // conv_pw_i8.hip: pointwise codes-to-codes layers with the weights resident in LDS (MobileOne's 1x1 layers)
 bool conv_pw_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
                      int32_t dilation, const ConvEpi& ep, const float* out, bool dual);

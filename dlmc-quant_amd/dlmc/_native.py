@@ -29,9 +29,10 @@ EMIT_SHIFT128 = 0x100    # DLMCQ_EMIT_SHIFT128: OR-able into q_form (include/dlm
 W2_CHUNK_MAJOR = 0x200   # DLMCQ_W2_CHUNK_MAJOR: OR-able into the chain entry points' last quantiser form
 FORCE_TILED = 0x400      # DLMCQ_FORCE_TILED: OR-able into q_form of conv2d_i8_nhwc_fused / _asym / _dual / conv2d_dw_i8_nhwc: the family's generic kernel
 ROUTE_ONLY = 0x800       # DLMCQ_ROUTE_ONLY: launch nothing, return which kernel the dispatch picks (ROUTE_*)
-ROUTE_TILED, ROUTE_HALO3X3, ROUTE_PW, ROUTE_PWR, ROUTE_DW, ROUTE_DWM = 1, 2, 3, 4, 5, 6
+PIPELINED = 0x1000       # DLMCQ_PIPELINED (opt-in): the persistent, software-pipelined halo-tile 3x3 kernel where it applies
+ROUTE_TILED, ROUTE_HALO3X3, ROUTE_PW, ROUTE_PWR, ROUTE_DW, ROUTE_DWM, ROUTE_HALO3X3_PIPE = 1, 2, 3, 4, 5, 6, 7
 ROUTE_TAG = {ROUTE_TILED: "conv_i8", ROUTE_HALO3X3: "conv3x3_halo", ROUTE_PW: "conv_pw", ROUTE_PWR: "conv_pwr", ROUTE_DW: "conv_dw",
-             ROUTE_DWM: "conv_dwm"}     # the profile tag (bench.py's kernel families) of each route
+             ROUTE_DWM: "conv_dwm", ROUTE_HALO3X3_PIPE: "conv3x3_pipe"}     # the profile tag (bench.py's kernel families) of each route
 Y_DEQUANT, Y_CODES = 0, 1
 CODES_NONE, CODES_I8, CODES_P4 = 0, 1, 2
 MINMAX_ABSMAX, MINMAX_MINMAX, MINMAX_NEGMIN = 0, 1, 2

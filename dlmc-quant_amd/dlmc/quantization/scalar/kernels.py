@@ -408,7 +408,7 @@ class EmitCodes:
 
 
 def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1,
-              residual=None, relu=False, emit=None, want_out=True, w_offset=None, force_tiled=False):
+              residual=None, relu=False, emit=None, want_out=True, w_offset=None, force_tiled=False, pipelined=False):
     """Fused int8 conv / linear on the matrix cores.  `codes`: uint8/int8 activation codes, logically
     (N, C, H, W) in channels_last memory, or (N, C) for a linear layer.  Returns fp32 (N, K, P, Q) in
     channels_last memory (or (N, K)).
@@ -418,7 +418,8 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
     well; the return value is then `(out, out_codes)`, `out` being None when `want_out=False`.
     `w_offset` ([K] fp32): asymmetric per-channel weights w' = qw * s_w[k] + w_offset[k] (dlmcq_conv2d_i8_nhwc_asym).
     `force_tiled` (DLMCQ_FORCE_TILED): the generic tiled kernel even where the library's dispatch would pick a specialised one -
-    the same results bit for bit; tests compare the two on one tensor, tools time them on one box."""
+    the same results bit for bit; tests compare the two on one tensor, tools time them on one box.  `pipelined` (DLMCQ_PIPELINED, opt-in):
+    the persistent, software-pipelined halo-tile 3x3 kernel where it applies (same bytes; measured slower than the plain one)."""
     N.require_gpu(codes, wq)
     linear = codes.dim() == 2
     if linear:
@@ -474,7 +475,7 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
             q_zp = None if emit.zero_point is None else _f32c(emit.zero_point, ref).reshape(-1)
             lo, hi, form, g = emit.lo, emit.hi, emit.form_arg, emit.g
         nbytes = codes.numel() + wq.numel() + out_elems * (4 * (out is not None) + 4 * (residual is not None) + (emit is not None))
-        form |= N.FORCE_TILED if force_tiled else 0
+        form |= (N.FORCE_TILED if force_tiled else 0) | (N.PIPELINED if pipelined else 0)
         if w_offset is not None:
             def call(extra=0):
                 return N.lib.dlmcq_conv2d_i8_nhwc_asym(

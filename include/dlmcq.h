@@ -89,12 +89,18 @@ typedef void* dlmcq_stream_t; /* hipStream_t */
  * bookkeeping (bench.py's per-kernel-family rooflines) cannot drift from what runs. */
 #define DLMCQ_FORCE_TILED 0x400
 #define DLMCQ_ROUTE_ONLY 0x800
+/* DLMCQ_PIPELINED (dlmcq_conv2d_i8_nhwc_fused; opt-in): a 3x3 / stride 1 layer of 128, 256 or 512 input channels with enough tiles runs on the
+ * persistent halo kernel that is software-pipelined across tiles (csrc/conv3x3_pipe_i8.hip: tile t's quantising epilogue under tile t + 1's
+ * K loop) instead of the plain halo-tile kernel.  Same bytes; measured 12 - 20 % SLOWER than the plain kernel (round 5, LABNOTES 15), hence
+ * not the default - kept built and tested for same-box A/B timing. */
+#define DLMCQ_PIPELINED 0x1000
 #define DLMCQ_ROUTE_TILED 1   /* conv_i8_mfma_kernel (csrc/conv_i8.hip) */
 #define DLMCQ_ROUTE_HALO3X3 2 /* conv3x3_halo_i8_kernel (csrc/conv3x3_i8.hip) */
 #define DLMCQ_ROUTE_PW 3      /* conv_pw_i8_kernel (csrc/conv_pw_i8.hip) */
 #define DLMCQ_ROUTE_PWR 4     /* conv_pwr_i8_kernel (csrc/conv_pwr_i8.hip) */
 #define DLMCQ_ROUTE_DW 5      /* conv_dw_i8_kernel / conv_dw3_i8_kernel / conv_dw3p2_i8_kernel (csrc/conv_dw_i8.hip) */
 #define DLMCQ_ROUTE_DWM 6     /* conv_dwm_i8_kernel (csrc/conv_dwm_i8.hip) */
+#define DLMCQ_ROUTE_HALO3X3_PIPE 7 /* conv3x3_pipe_i8_kernel (csrc/conv3x3_pipe_i8.hip) */
 
 /* ---- what is written to `y` ---- */
 #define DLMCQ_Y_DEQUANT 0 /* the fake-quantised value y */

@@ -173,3 +173,91 @@ def test_shifted_code_emission_is_the_same_network():
     with pytest.raises((DlmcqError, ValueError)):
         K.conv2d_i8_chain(a, b, res, relu=True, emit=K.EmitCodes(e1.scale, e1.zero_point, 0, 255, N.FORM_ZEROPOINT, shift128=True),
                           want_out=True, want_codes=True, relu2=True, emit2=emit(False))
+
+
+# csrc/conv3x3_pipe_i8.hip (round 5): N, C, H, W, K, unsigned input codes, input zero point, bias
+PIPE_SHAPES = [
+    (512, 256, 14, 14, 256, False, 0.0, True),     # BASELINE configs[2] / [3] at the stated size: ResNet-50 stage 3, RepVGG-A1 stage 3
+    (512, 512, 7, 7, 512, False, 0.0, True),       # ResNet-50 stage 4: 72 K steps per tile, four column blocks
+    (160, 128, 28, 28, 128, True, 0.0, True),      # two chunks per tile (the shortest loop: a quad per half-step), uint8 codes (re-centred on read)
+    (256, 128, 14, 14, 384, False, -128.0, False), # three column blocks (tile -> (row block, column block) by a division by 3), re-centred codes' zero point
+    (600, 256, 17, 13, 128, True, 5.0, True),      # odd image sizes, a zero point: border positions read its code; tiles crossing images
+    (600, 512, 9, 11, 256, False, 0.0, False),
+]
+
+
+@pytest.mark.parametrize("shape", PIPE_SHAPES, ids=lambda s: "x".join(str(int(v)) if not isinstance(v, bool) else "ft"[v] for v in s))
+def test_pipelined_halo_kernel_is_the_halo_kernel_and_the_tiled_kernel_bit_for_bit(shape):
+    """The persistent, software-pipelined 3x3 kernel (tile t's quantising epilogue under tile t + 1's K loop) against the plain halo kernel
+    (the default) and the tiled kernel (DLMCQ_FORCE_TILED) on the WHOLE tensor: the same codes byte for byte - first / last tile of a
+    workgroup, tiles that start a new column block, the overhang of the last row block - and a float64 reference on a sample."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    n, c, h, w, k, unsigned, zp, with_bias = shape
+    g = torch.Generator(device=DEV).manual_seed(n + c + k + h)
+    lo, hi = (0, 256) if unsigned else (-128, 128)
+    codes = torch.randint(lo, hi, (n, c, h, w), generator=g, device=DEV, dtype=torch.int16).to(torch.uint8 if unsigned else torch.int8)
+    codes = codes.contiguous(memory_format=torch.channels_last)
+    wq = torch.randint(-127, 128, (k, 3, 3, c), generator=g, device=DEV, dtype=torch.int8)
+    wsum = wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
+    s_w = (torch.rand(k, generator=g, device=DEV) * 2e-4 + 5e-5).contiguous()
+    bias = (torch.randn(k, generator=g, device=DEV) * 0.5).contiguous() if with_bias else None
+    s_in, in_zp = torch.full((1,), 0.021, device=DEV), torch.full((1,), zp, device=DEV)
+    q_scale = torch.full((1,), 0.05, device=DEV)
+    emit = K.EmitCodes(q_scale, None, 0, 255, N.FORM_ZEROPOINT)
+
+    def run(**kw):
+        K.PROFILE.reset()
+        K.PROFILE.enabled = True
+        try:
+            _, got = K.conv2d_i8(codes, wq, wsum, bias, s_in, in_zp, s_w, padding=1, relu=True, emit=emit, want_out=False, **kw)
+        finally:
+            K.PROFILE.enabled = False
+        tag = K.PROFILE.records[-1][0]
+        K.PROFILE.reset()
+        return got, tag
+    got, tag = run(pipelined=True)
+    assert tag == "conv3x3_pipe", tag
+    plain, tag = run()
+    assert tag == "conv3x3_halo", tag
+    assert torch.equal(got, plain), f"{int((got != plain).sum())} of {got.numel()} codes differ from the plain halo kernel"
+    del plain
+    tiled, tag = run(force_tiled=True)
+    assert tag == "conv_i8", tag
+    assert torch.equal(got, tiled), f"{int((got != tiled).sum())} of {got.numel()} codes differ from the tiled kernel"
+    del tiled
+    # float64 reference on the first, a middle and the last image
+    for i in sorted({0, n // 2, n - 1}):
+        x = (codes[i:i + 1].to(torch.int16).double().cpu() - zp) * 0.021
+        wd = wq[:, :, :, :].permute(0, 3, 1, 2).double().cpu() * s_w.double().cpu().reshape(-1, 1, 1, 1)
+        ref = torch.relu(F.conv2d(x, wd, None if bias is None else bias.double().cpu(), padding=1))
+        want = torch.clamp(torch.round(ref / 0.05), 0, 255)
+        diff = (got[i:i + 1].double().cpu() - want).abs()
+        assert float(diff.max()) <= 1.0 and float((diff > 0).double().mean()) < 2e-3, (i, float(diff.max()), float((diff > 0).double().mean()))
+
+
+def test_pipelined_halo_kernel_leaves_small_and_other_layers_to_the_halo_kernel():
+    """Asked for (DLMCQ_PIPELINED) but not applicable - fewer than two tiles per CU, 64 input channels, stride 2, a zero point in the consumer's quantiser: the plain halo kernel as before."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator(device=DEV).manual_seed(3)
+
+    def tag_of(n, c, h, k, stride=1, q_zp=None):
+        codes = torch.randint(-128, 128, (n, c, h, h), generator=g, device=DEV, dtype=torch.int16).to(torch.int8).contiguous(memory_format=torch.channels_last)
+        wq = torch.randint(-127, 128, (k, 3, 3, c), generator=g, device=DEV, dtype=torch.int8)
+        wsum = wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
+        emit = K.EmitCodes(torch.full((1,), 0.05, device=DEV), q_zp, 0, 255, N.FORM_ZEROPOINT)
+        K.PROFILE.reset()
+        K.PROFILE.enabled = True
+        try:
+            K.conv2d_i8(codes, wq, wsum, None, torch.full((1,), 0.02, device=DEV), None, torch.full((k,), 1e-4, device=DEV), stride=stride, padding=1,
+                        relu=True, emit=emit, want_out=False, pipelined=True)
+        finally:
+            K.PROFILE.enabled = False
+        t = K.PROFILE.records[-1][0]
+        K.PROFILE.reset()
+        return t
+    assert tag_of(64, 256, 14, 256) == "conv3x3_halo"                                        # 114 tiles
+    assert tag_of(64, 64, 56, 64) == "conv3x3_halo"                                          # 64 input channels
+    assert tag_of(256, 256, 28, 256, stride=2) == "conv3x3_halo"                             # stride 2
+    assert tag_of(512, 256, 14, 256, q_zp=torch.full((1,), 3.0, device=DEV)) == "conv3x3_halo"   # not the plain quantiser
