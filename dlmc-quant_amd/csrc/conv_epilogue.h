@@ -26,6 +26,12 @@ struct ConvEpi {
   int relu;
   uint32_t q_xor;          // 0x80808080 when the codes are stored as int8 `code - 128` (DLMCQ_EMIT_SHIFT128), else 0
   uint32_t ctl;            // host side only: DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY | DLMCQ_PIPELINED as passed in `q_form`
+  // observer partials of the fp32 OUTPUT (dlmcq_conv2d_i8_nhwc_fused_observed; the tiled kernel only): every workgroup writes the
+  // (max, min, max of |x|'s bits) of the values it stored at entry blockIdx.x of three planes of `mm_np` floats each - observer.hip's
+  // partial layout, reduced by dlmcq_minmax_finalize_f32.  The calibrating first batch: the consumer's min/max pass (one read of the
+  // tensor: modules/base.py:82-94 -> ops.py:20-34) comes out of the launch that produces the tensor.
+  float* mm;
+  int mm_np;
 };
 
 // `q_form` argument of an entry point -> (form, shifted-emission flag); false = invalid

@@ -472,6 +472,44 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
 #pragma unroll
     for (int i = 0; i < 16; ++i) s0r[ASYM ? i : 0] = (float)tab[(i & 3) + 8 * (i >> 2) + 4 * hsel];
   }
+  // observer partials of the stored fp32 values (ep.mm; observer.hip's accumulator: max, min, unsigned max of |x|'s bits = the NaN detector)
+  float mm_mx = -__builtin_inff(), mm_mn = __builtin_inff();
+  uint32_t mm_ab = 0u;
+  auto mm_add = [&](float v) {
+    mm_ab = max(mm_ab, __float_as_uint(v) & 0x7fffffffu);
+    mm_mx = __builtin_fmaxf(mm_mx, v);
+    mm_mn = __builtin_fminf(mm_mn, v);
+  };
+  auto mm_flush = [&]() {          // wave butterfly, the four waves through LDS, one partial per workgroup
+    if (!ep.mm) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mm_ab = max(mm_ab, (uint32_t)__shfl_xor((int)mm_ab, off, 64));
+      mm_mx = __builtin_fmaxf(mm_mx, __shfl_xor(mm_mx, off, 64));
+      mm_mn = __builtin_fminf(mm_mn, __shfl_xor(mm_mn, off, 64));
+    }
+    __syncthreads();                 // (every wave is done with the stage)
+    float* red = reinterpret_cast<float*>(lds);
+    if (lane == 0) {
+      red[wave * 3] = mm_mx;
+      red[wave * 3 + 1] = mm_mn;
+      reinterpret_cast<uint32_t*>(red)[wave * 3 + 2] = mm_ab;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float mx = red[0], mn = red[1];
+      uint32_t ab = reinterpret_cast<uint32_t*>(red)[2];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        mx = __builtin_fmaxf(mx, red[k * 3]);
+        mn = __builtin_fminf(mn, red[k * 3 + 1]);
+        ab = max(ab, reinterpret_cast<uint32_t*>(red)[k * 3 + 2]);
+      }
+      ep.mm[blockIdx.x] = mx;
+      ep.mm[ep.mm_np + blockIdx.x] = mn;
+      reinterpret_cast<uint32_t*>(ep.mm)[2 * ep.mm_np + blockIdx.x] = ab;
+    }
+  };
   if ((g.K & 3) == 0) {
     // through LDS: accumulator layout (lane = channel, register = row) -> row-major, so that each lane stores 16 B and
     // each wave-instruction writes 4 rows x 256 contiguous bytes (the 1x1 layers are bound by this output stream).
@@ -517,6 +555,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
           if (ep.residual) v = f32x4{v.x + idt[it].x, v.y + idt[it].y, v.z + idt[it].z, v.w + idt[it].w};
           if (ep.relu) v = f32x4{relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)};
           if (out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + at));
+          if (ep.mm) { mm_add(v.x); mm_add(v.y); mm_add(v.z); mm_add(v.w); }
           if (ep.codes) {
             const uint32_t c = eq.code4(v);
             if (wide_codes) cw[h][it] = c;
@@ -550,6 +589,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wgt[3] = __builtin_readcyclecounter();
     }
+    mm_flush();
     return;
   }
   // K % 4 != 0 (e.g. a 1000-class head): element-wise stores straight from the accumulator layout
@@ -568,9 +608,11 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
       if (ep.residual) v = v + ep.residual[at];
       if (ep.relu) v = relu_nan(v);
       if (out) __builtin_nontemporal_store(v, out + at);
+      if (ep.mm) mm_add(v);
       if (ep.codes) ep.codes[at] = (uint8_t)eq.exact(v);
     }
   }
+  mm_flush();
 }
 
 // Weights fp32 KCRS -> int8 KRSC codes (form SYMMETRIC, FSPTQuant/base.py:149-152: q = clamp(R(w/s_k), lo, hi))
@@ -657,8 +699,11 @@ static ConvPlan conv_plan(int64_t C, int64_t K, int64_t R, int64_t S, bool dual)
 static int conv_launch(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
                        const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N, int64_t H,
                        int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride, int32_t pad,
-                       int32_t dilation, int32_t x_is_unsigned, dlmcq_stream_t stream, const ConvEpi& ep = ConvEpi{},
-                       const ConvSeg2* seg2 = nullptr, const ConvPlan* forced = nullptr) {
+                       int32_t dilation, int32_t x_is_unsigned, dlmcq_stream_t stream, const ConvEpi& ep_in = ConvEpi{},
+                       const ConvSeg2* seg2 = nullptr, const ConvPlan* forced = nullptr, int64_t* mm_count = nullptr) {
+  // (observer partials - ep.mm - come from the tiled kernel's fp32 epilogue only: a call another kernel takes reports 0 partials)
+  ConvEpi ep = ep_in;
+  if (mm_count) *mm_count = 0;
   if (N < 0 || H < 1 || W < 1 || C < 1 || K < 1 || R < 1 || S < 1 || stride < 1 || pad < 0 || dilation < 1)
     return DLMCQ_EINVAL;
   if (C % CV_BK != 0) return DLMCQ_EINVAL;  // the K step is 64 input channels
@@ -694,6 +739,8 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   // the specialised kernels, unless the caller (DLMCQ_FORCE_TILED) or a lab plan keeps the call on this file's kernel;
   // DLMCQ_ROUTE_ONLY: the decision is the answer, nothing is launched
   const bool special = plan.halo && !(ep.ctl & DLMCQ_FORCE_TILED), route_only = (ep.ctl & DLMCQ_ROUTE_ONLY) != 0;
+  float* const mm_req = ep.mm;
+  ep.mm = nullptr;                    // (the specialised kernels below do not write partials)
   if (special && conv_pw_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
     return route_only ? DLMCQ_ROUTE_PW : conv_pw_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, shift, ep, st);
   if (special && conv_pwr_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2))
@@ -717,7 +764,7 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
     ConvPlan p2 = plan;                  // (fp32 outputs, shortcuts, asymmetric weights: the 128-wide kernels)
     p2.bn = 128;
     return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
-                       x_is_unsigned, stream, ep, seg2, &p2);
+                       x_is_unsigned, stream, ep_in, seg2, &p2, mm_count);
   }
   g.nblk_m = (int)((M + CV_BM - 1) / CV_BM);
   g.nblk_n = (int)((K + plan.bn - 1) / plan.bn);
@@ -731,6 +778,11 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
     if (s2.g.M != g.M || s2.g.K != g.K || s2.g.P != g.P || s2.g.Q != g.Q || ep.w_off) return DLMCQ_EINVAL;
   }
   if (route_only) return DLMCQ_ROUTE_TILED;
+  if (mm_req && out) {                             // one partial per workgroup of this launch
+    ep.mm = mm_req;
+    ep.mm_np = (int)nwg;
+    if (mm_count) *mm_count = nwg;
+  }
 #define DLMCQ_CONV_ARGS dim3((uint32_t)nwg), dim3(256), 0, st, xs, w, out, bias, wsum, in_scale, in_zero_point, w_scale, g, shift, ep, s2
   if (seg2) {
     if (plan.bn == 64) hipLaunchKernelGGL((conv_i8_mfma_kernel<64, true, true>), DLMCQ_CONV_ARGS);
@@ -798,6 +850,28 @@ extern "C" int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float*
   const ConvEpi ep = make_epi(residual, relu, codes, q_scale, q_zero_point, q_lo, q_hi, q_form, q_ste_g);
   return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
                      x_is_unsigned, stream, ep);
+}
+
+extern "C" size_t dlmcq_conv2d_i8_observed_partials(int64_t M, int64_t K) {
+  if (M < 0 || K < 1) return 0;
+  return (size_t)(((M + CV_BM - 1) / CV_BM) * ((K + 63) / 64));      // the tiled kernel's finest tiling: 128 pixels x 64 channels per workgroup
+}
+
+extern "C" int dlmcq_conv2d_i8_nhwc_fused_observed(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                                                   const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N,
+                                                   int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride,
+                                                   int32_t pad, int32_t dilation, int32_t x_is_unsigned, const float* residual,
+                                                   int32_t relu, void* codes, const float* q_scale, const float* q_zero_point,
+                                                   int32_t q_lo, int32_t q_hi, int32_t q_form, float q_ste_g, float* partials,
+                                                   int64_t partials_capacity, int64_t* partials_count, dlmcq_stream_t stream) {
+  if (!partials || !partials_count || !out) return DLMCQ_EINVAL;
+  const int64_t P = (H + 2 * pad - dilation * (R - 1) - 1) / (stride > 0 ? stride : 1) + 1;
+  const int64_t Q = (W + 2 * pad - dilation * (S - 1) - 1) / (stride > 0 ? stride : 1) + 1;
+  if (partials_capacity < (int64_t)dlmcq_conv2d_i8_observed_partials(N * P * Q, K)) return DLMCQ_ESCRATCH;
+  ConvEpi ep = make_epi(residual, relu, codes, q_scale, q_zero_point, q_lo, q_hi, q_form, q_ste_g);
+  ep.mm = partials;
+  return conv_launch(x, w, out, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, R, S, stride, pad, dilation,
+                     x_is_unsigned, stream, ep, nullptr, nullptr, partials_count);
 }
 
 extern "C" int dlmcq_conv2d_i8_nhwc_asym(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,

@@ -286,6 +286,23 @@ __global__ __launch_bounds__(DLMCQ_BLOCK) void finalize_tensor_kernel(const floa
   if (threadIdx.x == 0) finalize_write(a, 0, f);
 }
 
+// ... the same over `np` partials whose three planes are `stride` entries apart (dlmcq_minmax_finalize_f32: partials written by the
+// epilogue of a convolution launch, one per workgroup)
+__global__ __launch_bounds__(DLMCQ_BLOCK) void finalize_planes_kernel(const float* __restrict__ scratch, int64_t np, int64_t stride,
+                                                                     Finalize f) {
+  Acc a;
+  acc_init<DLMCQ_MINMAX_MINMAX>(a);
+  for (int64_t i = threadIdx.x; i < np; i += DLMCQ_BLOCK) {
+    Acc b;
+    b.mx = scratch[i];
+    b.mn = scratch[stride + i];
+    b.ab = reinterpret_cast<const uint32_t*>(scratch)[2 * stride + i];
+    acc_merge<DLMCQ_MINMAX_MINMAX>(a, b);
+  }
+  a = block_reduce<DLMCQ_MINMAX_MINMAX>(a);
+  if (threadIdx.x == 0) finalize_write(a, 0, f);
+}
+
 // Per channel: thread c folds its nseg partials (coalesced across c).
 __global__ __launch_bounds__(DLMCQ_BLOCK) void finalize_rows_kernel(const float* __restrict__ scratch, int64_t nseg,
                                                                    int64_t channels, Finalize f) {
@@ -456,6 +473,21 @@ extern "C" int dlmcq_observe_qparams_f32(const float* x, float* scale, float* of
   const int mode = is_signed ? DLMCQ_MINMAX_ABSMAX : DLMCQ_MINMAX_MINMAX;
   f.mode = mode;
   return run_observer(x, outer, channels, inner, mode, f, scratch, scratch_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int dlmcq_minmax_finalize_f32(const float* partials, int64_t count, int64_t plane_stride, float* out_max, float* out_min,
+                                         int32_t mode, dlmcq_stream_t stream) {
+  if (count < 1 || plane_stride < count || !partials || !out_max || mode < DLMCQ_MINMAX_ABSMAX || mode > DLMCQ_MINMAX_NEGMIN ||
+      (mode != DLMCQ_MINMAX_ABSMAX && !out_min))
+    return DLMCQ_EINVAL;
+  Finalize f{};
+  f.out_a = out_max;
+  f.out_b = out_min;
+  f.qparams = 0;
+  f.mode = mode;
+  hipLaunchKernelGGL(finalize_planes_kernel, dim3(1), dim3(DLMCQ_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), partials, count,
+                     plane_stride, f);
+  return launch_status();
 }
 
 extern "C" int dlmcq_qparams_from_minmax(const float* vmax, const float* vmin, float* scale, float* offset,

@@ -48,6 +48,10 @@ SIGNATURES = {
     "dlmcq_dequant_f32": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "dlmcq_minmax_scratch_bytes": (_sz, [_i64, _i64, _i64]),
     "dlmcq_minmax_f32": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i64, _i32, _p, _sz, _p]),
+    "dlmcq_minmax_finalize_f32": (ctypes.c_int, [_p, _i64, _i64, _p, _p, _i32, _p]),
+    "dlmcq_conv2d_i8_observed_partials": (_sz, [_i64, _i64]),
+    "dlmcq_conv2d_i8_nhwc_fused_observed": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32,
+                                                            _i32, _i32, _p, _i32, _p, _p, _p, _i32, _i32, _i32, _f32, _p, _i64, _p, _p]),
     "dlmcq_qparams_from_minmax": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f32, _p]),
     "dlmcq_span_scale_f32": (ctypes.c_int, [_p, _p, _p, _i64, _f32, _i32, _p]),
     "dlmcq_lsq_init_scratch_bytes": (_sz, [_i64]),

@@ -18,7 +18,7 @@ from torch.nn import Module
 from .... import _native as N
 from .. import kernels as K
 from .. import ops
-from .._wrapper import InitState, fake_quant, fusable_epilogue, int8_forward, int8_gemm_default, int8_kind, set_scale
+from .._wrapper import InitState, ZeroPointSpeculation, fake_quant, fusable_epilogue, int8_forward, int8_gemm_default, int8_kind, set_scale
 from ..utils import get_qrange
 
 
@@ -93,7 +93,10 @@ class FSPTQBase(Module):
             return False
         if not (0 <= self.in_min_val and self.in_max_val <= 255) and not (-128 <= self.in_min_val and self.in_max_val <= 127):
             return False
-        if self._zp_is_int is None:   # one host read, right after calibration
+        if self._zp_is_int is None:   # one host read, right after calibration - or none: the caller collects them (ZeroPointSpeculation)
+            if ZeroPointSpeculation.active is not None:
+                ZeroPointSpeculation.active.pending.append(self)
+                return True
             zp = float(self.in_offset.reshape(-1)[0])
             self._zp_is_int = zp == round(zp) and self.in_min_val <= zp <= self.in_max_val
         return self._zp_is_int
@@ -136,11 +139,17 @@ class FSPTQBase(Module):
             kw["sync"] = True
         if "channel" in str(cfg["type"]):
             kw.setdefault("ch_axis", 1)
+        if cfg["type"] == "minmax_tensor":       # (round 5: the producing launch may have observed this very tensor in its epilogue)
+            hint = K.minmax_hint(input)
+            if hint is not None:
+                kw["minmax_hint"] = hint
         scale, offset = ops.get_qparams_tensor(input.detach(), qtype=cfg["type"], **kw)
         set_scale(self.in_scale, scale)
         self.in_offset = offset.detach().to(torch.float32)
         self._zp_is_int = None
         self._init.mark(self, "in_init_state")
+        if ZeroPointSpeculation.active is not None:
+            ZeroPointSpeculation.active.calibrated.append(self)
 
     def _calibrate_weight(self):
         cfg = self.qconfig["weight"]
@@ -151,7 +160,7 @@ class FSPTQBase(Module):
             self.init_alpha()
         self._init.mark(self, "wt_init_state")
 
-    def forward_fused(self, input, residual=None, relu=False):
+    def forward_fused(self, input, residual=None, relu=False, observe_out=False):
         """`forward(input)` followed by `+ residual` and ReLU as ONE int8 launch - observers and calibration exactly as in
         `forward` - when this layer takes its int8 route; None when it does not (the caller then runs the ops one by one;
         whatever calibration was due has been done).  Used by dlmc.utils.fuse.EagerFused."""
@@ -163,7 +172,7 @@ class FSPTQBase(Module):
         if not (fusable_epilogue(self) and self._int8_applicable(input)):
             return None
         return int8_forward(self, input, self.in_scale, self.in_offset, self.in_min_val, self.in_max_val, N.FORM_ZEROPOINT,
-                            self.wt_scale, self.wt_min_val, self.wt_max_val, residual=residual, relu=relu)
+                            self.wt_scale, self.wt_min_val, self.wt_max_val, residual=residual, relu=relu, observe_out=observe_out)
 
     def forward(self, input):
         N.require_gpu(input, self.weight)

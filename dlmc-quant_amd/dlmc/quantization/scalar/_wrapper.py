@@ -116,6 +116,47 @@ def sync_enabled():
 ALLREDUCE_CALLS = 0     # collectives actually issued by this process (bench.py reports the count of the calibrating forward)
 
 
+class ZeroPointSpeculation:
+    """One host read per calibrating forward instead of one per layer (round 5: the first batch).
+
+    Whether a freshly calibrated FSPTQ layer may take its int8 route depends on a value that lives on the device: its zero point (the
+    observed minimum, FSPTQuant/base.py:99-103) must be an integer of the code range.  Reading it right after calibration costs a
+    device -> host synchronisation per layer - 54 pipeline drains in ResNet-50's first forward.  Inside `with ZeroPointSpeculation() as sp:`
+    a layer that does not know yet ASSUMES an integer zero point (true for every post-ReLU tensor that holds a zero), takes the int8 route
+    and registers itself; `sp.verify()` then checks all of them with ONE read.  If a layer guessed wrong, everything behind it saw wrong
+    activations: `sp.rearm()` re-arms the observers that calibrated inside the block, and the caller runs the forward again without
+    speculation (dlmc.utils.fuse.EagerFused does) - the result is the unspeculated one either way."""
+    active = None
+
+    def __init__(self):
+        self.pending = []       # layers that assumed an integer zero point
+        self.calibrated = []    # layers whose input observer ran inside the block
+
+    def __enter__(self):
+        self._outer, ZeroPointSpeculation.active = ZeroPointSpeculation.active, self
+        return self
+
+    def __exit__(self, *exc):
+        ZeroPointSpeculation.active = self._outer
+        return False
+
+    def verify(self):
+        """Settle every pending layer's `_zp_is_int` with one host read; True when every assumption held."""
+        if not self.pending:
+            return True
+        zp = torch.stack([m.in_offset.detach().reshape(-1)[0].float() for m in self.pending])
+        lo = torch.tensor([float(m.in_min_val) for m in self.pending], device=zp.device)
+        hi = torch.tensor([float(m.in_max_val) for m in self.pending], device=zp.device)
+        ok = ((zp == torch.round(zp)) & (zp >= lo) & (zp <= hi)).cpu().tolist()      # the one synchronisation
+        for m, good in zip(self.pending, ok):
+            m._zp_is_int = bool(good)
+        return all(ok)
+
+    def rearm(self):
+        for m in self.calibrated:
+            m._init.mark(m, "in_init_state", False)
+
+
 def allreduce_minmax(vmax, neg_vmin=None, group=None):
     """The path's only collective (C2): one all_reduce(MAX) over the packed [max | -min] vector.
     Exact and order-independent, so every rank ends with the single-GPU result over the whole batch.
@@ -139,19 +180,25 @@ def allreduce_minmax(vmax, neg_vmin=None, group=None):
     return buf[:n].reshape(vmax.shape), buf[n:].reshape(neg_vmin.shape)
 
 
-def observe_minmax(x, n_bits, signed, ch_axis=None, allow_offset=True, scale_eps=0.0, sync=False):
+def observe_minmax(x, n_bits, signed, ch_axis=None, allow_offset=True, scale_eps=0.0, sync=False, hint=None):
     """quantize_minmax_{tensor,channel} on device.  `sync=True` (activations under data parallelism)
-    inserts the all-reduce between the reduction and the scale/offset arithmetic."""
+    inserts the all-reduce between the reduction and the scale/offset arithmetic.  `hint` (per tensor only): the observer partials
+    the launch that produced `x` left behind (K.minmax_hint) - the min/max pass over `x` is then a reduction of those few thousand
+    values instead of one more read of the tensor (the same max and min, exactly)."""
     import torch.distributed as dist
-    if not (sync and sync_enabled() and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if ch_axis is not None:
+        hint = None
+    if hint is None and not (sync and sync_enabled() and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return K.observe_qparams(x, n_bits, signed, ch_axis=ch_axis, allow_offset=allow_offset, scale_eps=scale_eps)
+    do_sync = sync and sync_enabled() and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    reduce = allreduce_minmax if do_sync else (lambda a, b=None: (a, b))
     if signed:
-        vmax, _ = K.minmax(x, ch_axis=ch_axis, mode=N.MINMAX_ABSMAX)
-        vmax, _ = allreduce_minmax(vmax.reshape(-1))
+        vmax, _ = K.minmax_from_partials(*hint, mode=N.MINMAX_ABSMAX) if hint else K.minmax(x, ch_axis=ch_axis, mode=N.MINMAX_ABSMAX)
+        vmax, _ = reduce(vmax.reshape(-1))
         s, o = K.qparams_from_minmax(vmax, None, n_bits, True, scale_eps=scale_eps)
     else:
-        vmax, nmin = K.minmax(x, ch_axis=ch_axis, mode=N.MINMAX_NEGMIN)
-        vmax, nmin = allreduce_minmax(vmax.reshape(-1), nmin.reshape(-1))
+        vmax, nmin = K.minmax_from_partials(*hint, mode=N.MINMAX_NEGMIN) if hint else K.minmax(x, ch_axis=ch_axis, mode=N.MINMAX_NEGMIN)
+        vmax, nmin = reduce(vmax.reshape(-1), nmin.reshape(-1))
         s, o = K.qparams_from_minmax(vmax, nmin, n_bits, False, allow_offset=allow_offset, min_is_negated=True,
                                      scale_eps=scale_eps)
     if ch_axis is None:
@@ -217,7 +264,7 @@ def _cached_weight_codes(mod, wt_scale, wt_lo, wt_hi, quantise, scale_key=None):
 
 
 def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, wt_lo, wt_hi, g_in=0.0, wt_scale_key=None,
-                 residual=None, relu=False):
+                 residual=None, relu=False, observe_out=False):
     """Quantise the activation to integer codes (one pass, 4 B read + 1 B written per element), quantise the
     weight to KRSC int8, and contract on v_mfma_i32_32x32x32_i8 with the dequantisation fused into the epilogue.
     Same mathematical result as F.conv2d(fake_quant(x), fake_quant(w), bias); activations travel channels_last.
@@ -242,7 +289,7 @@ def int8_forward(mod, input, in_scale, in_zp, in_lo, in_hi, act_form, wt_scale, 
         out = K.conv2d_i8(flat, wq, wsum, mod.bias, in_scale, in_zp, wt_scale)
         return out.reshape(*codes.shape[:-1], out.shape[-1])
     return K.conv2d_i8(codes, wq, wsum, mod.bias, in_scale, in_zp, wt_scale, stride=mod.stride[0],
-                       padding=mod.padding[0], dilation=mod.dilation[0], residual=residual, relu=bool(relu))
+                       padding=mod.padding[0], dilation=mod.dilation[0], residual=residual, relu=bool(relu), observe=bool(observe_out))
 
 
 def fusable_epilogue(mod):

@@ -5,6 +5,8 @@ The arithmetic happens in libdlmcq.so; tensors that are not on the GPU are refus
 """
 import math
 
+import ctypes
+
 import torch
 
 from ... import _native as N
@@ -184,6 +186,22 @@ def minmax(x, ch_axis=None, mode=MINMAX_MINMAX):
     if ch_axis is None:
         return vmax.reshape(()), (None if vmin is None else vmin.reshape(()))
     return vmax, vmin
+
+
+def minmax_hint(x):
+    """The observer partials a producing launch left on tensor `x` (conv2d_i8(..., observe=True)), if `x` is still what that launch wrote."""
+    h = getattr(x, "_dlmcq_mm", None)
+    return (h[0], h[1]) if h is not None and h[2] == x._version else None
+
+
+def minmax_from_partials(partials, count, mode=MINMAX_MINMAX):
+    """(max, min) - 0-dim tensors - of the tensor whose per-workgroup observer partials a producing launch wrote (three planes of
+    `count` floats: dlmcq_conv2d_i8_nhwc_fused_observed); dlmcq_minmax_finalize_f32.  mode as in `minmax`."""
+    vmax = torch.empty(1, dtype=torch.float32, device=partials.device)
+    vmin = torch.empty(1, dtype=torch.float32, device=partials.device) if mode != MINMAX_ABSMAX else None
+    PROFILE.launch("observer", count * 12, lambda: N.check(N.lib.dlmcq_minmax_finalize_f32(
+        N.ptr(partials), int(count), int(count), N.ptr(vmax), N.ptr(vmin), int(mode), N.stream_ptr())))
+    return vmax.reshape(()), (None if vmin is None else vmin.reshape(()))
 
 
 def observe_qparams(x, n_bits, signed, ch_axis=None, allow_offset=True, scale_eps=0.0):
@@ -408,7 +426,7 @@ class EmitCodes:
 
 
 def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1,
-              residual=None, relu=False, emit=None, want_out=True, w_offset=None, force_tiled=False, pipelined=False):
+              residual=None, relu=False, emit=None, want_out=True, w_offset=None, force_tiled=False, pipelined=False, observe=False):
     """Fused int8 conv / linear on the matrix cores.  `codes`: uint8/int8 activation codes, logically
     (N, C, H, W) in channels_last memory, or (N, C) for a linear layer.  Returns fp32 (N, K, P, Q) in
     channels_last memory (or (N, K)).
@@ -419,7 +437,9 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
     `w_offset` ([K] fp32): asymmetric per-channel weights w' = qw * s_w[k] + w_offset[k] (dlmcq_conv2d_i8_nhwc_asym).
     `force_tiled` (DLMCQ_FORCE_TILED): the generic tiled kernel even where the library's dispatch would pick a specialised one -
     the same results bit for bit; tests compare the two on one tensor, tools time them on one box.  `pipelined` (DLMCQ_PIPELINED, opt-in):
-    the persistent, software-pipelined halo-tile 3x3 kernel where it applies (same bytes; measured slower than the plain one)."""
+    the persistent, software-pipelined halo-tile 3x3 kernel where it applies (same bytes; measured slower than the plain one).
+    `observe` (dlmcq_conv2d_i8_nhwc_fused_observed; needs the fp32 output): the launch also leaves the observer partials of its output -
+    `out._dlmcq_mm = (partials, count, version)` when the kernel that ran has the observing epilogue; `minmax_from_partials` reduces them."""
     N.require_gpu(codes, wq)
     linear = codes.dim() == 2
     if linear:
@@ -438,7 +458,7 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
         if linear:
             return torch.empty((n, K), dtype=dtype, device=codes.device)
         return torch.empty((n, K, P, Q), dtype=dtype, device=codes.device, memory_format=torch.channels_last)
-    fused = residual is not None or relu or emit is not None or w_offset is not None
+    fused = residual is not None or relu or emit is not None or w_offset is not None or (observe and want_out)
     if not want_out and emit is None:
         raise ValueError("conv2d_i8: nothing to produce (want_out=False without emit)")
     if w_offset is not None:
@@ -481,6 +501,15 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
                 return N.lib.dlmcq_conv2d_i8_nhwc_asym(
                     *args[:8], N.ptr(w_offset), *args[8:], N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp),
                     lo, hi, form | extra, g, N.stream_ptr())
+        elif observe and out is not None:
+            cap = int(N.lib.dlmcq_conv2d_i8_observed_partials(n * P * Q, K))
+            partials = torch.empty(3 * cap, dtype=torch.float32, device=codes.device)
+            count = ctypes.c_int64(0)
+
+            def call(extra=0):
+                return N.lib.dlmcq_conv2d_i8_nhwc_fused_observed(
+                    *args, N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form | extra, g,
+                    N.ptr(partials), 3 * cap, ctypes.byref(count), N.stream_ptr())
         else:
             def call(extra=0):
                 return N.lib.dlmcq_conv2d_i8_nhwc_fused(
@@ -488,6 +517,8 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
                     N.stream_ptr())
         tag = N.ROUTE_TAG[N.route(call(N.ROUTE_ONLY))] if PROFILE.enabled else "conv_i8"
         PROFILE.launch(tag, nbytes, lambda: N.check(call()), ops)
+        if observe and out is not None and w_offset is None and count.value > 0:
+            out._dlmcq_mm = (partials, int(count.value), out._version)      # (an in-place write to `out` later invalidates it: the version is checked)
         return (out, out_codes) if emit is not None else out
     if force_tiled:
         raise ValueError("conv2d_i8: force_tiled needs an epilogue (the plain fp32 entry point always runs the tiled kernel)")

@@ -129,7 +129,7 @@ class QBase(Module):
         self._init.mark(self, "wt_init_state")
 
     # ----------------------------------------------------------------------------- forward
-    def forward_fused(self, input, residual=None, relu=False):
+    def forward_fused(self, input, residual=None, relu=False, observe_out=False):      # (observe_out: FSPTQ family only so far)
         """`forward(input)` followed by `+ residual` and ReLU as ONE int8 launch (observers and calibration as in `forward`)
         when this layer takes its int8 route; None when it does not.  Used by dlmc.utils.fuse.EagerFused."""
         N.require_gpu(input, self.weight)

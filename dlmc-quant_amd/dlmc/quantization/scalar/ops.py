@@ -28,10 +28,11 @@ def l2_loss(t1, t2):
 
 
 # ------------------------------------------------------------------------------ min / max
-def quantize_minmax_tensor(tensor, n_bits, signed, allow_offset=True, sync=False):
+def quantize_minmax_tensor(tensor, n_bits, signed, allow_offset=True, sync=False, minmax_hint=None):
     """ops.py:20-34.  Returns 0-dim fp32 device tensors (the reference's signed offset is an int64
-    CPU `tensor(0)`; it only ever enters fp32 arithmetic)."""
-    s, o = observe_minmax(tensor.detach(), n_bits, signed, None, allow_offset, sync=sync)
+    CPU `tensor(0)`; it only ever enters fp32 arithmetic).  `minmax_hint` (this build's own callers): observer partials the launch
+    that produced `tensor` left behind (kernels.minmax_hint) - the same max / min without another read of the tensor."""
+    s, o = observe_minmax(tensor.detach(), n_bits, signed, None, allow_offset, sync=sync, hint=minmax_hint)
     if not signed and not allow_offset:
         _assert_nonneg(tensor)
     return s, o

@@ -163,6 +163,11 @@ int dlmcq_minmax_f32(const float* x, float* out_max, float* out_min, int64_t out
                      int64_t channels, int64_t inner, int32_t mode, void* scratch,
                      size_t scratch_bytes, dlmcq_stream_t stream);
 
+/* The second stage of dlmcq_minmax_f32 alone, per tensor: `count` partials in three planes `plane_stride` floats apart ([max | min |
+ * bits of max |x|]: what a stage-1 kernel or dlmcq_conv2d_i8_nhwc_fused_observed wrote) -> out_max[0], out_min[0] as `mode` says. */
+int dlmcq_minmax_finalize_f32(const float* partials, int64_t count, int64_t plane_stride, float* out_max, float* out_min,
+                              int32_t mode, dlmcq_stream_t stream);
+
 /*
  * The arithmetic tail of quantize_minmax_{tensor,channel} on device (no host sync):
  *   signed  : scale = vmax / (2^(b-1)-1)              offset = 0         (vmax = max|x|)
@@ -382,6 +387,23 @@ int dlmcq_conv2d_i8_nhwc_fused(const void* x, const int8_t* w, float* out, const
                                int32_t x_is_unsigned, const float* residual, int32_t relu, void* codes,
                                const float* q_scale, const float* q_zero_point, int32_t q_lo, int32_t q_hi,
                                int32_t q_form, float q_ste_g, dlmcq_stream_t stream);
+
+/* dlmcq_conv2d_i8_nhwc_fused (out != NULL) that also OBSERVES its fp32 output - the calibrating first batch (round 5): the min/max pass
+ * of the consumer's activation observer (modules/base.py:82-94 / FSPTQuant/base.py:99-103 -> ops.py:20-34: one more read of the tensor) comes
+ * out of the epilogue of the launch that writes the tensor.  Every workgroup of the tiled kernel stores the (max, min, unsigned max of the
+ * bits of |v| - the NaN detector) of the values it wrote as entry i of three planes of `*partials_count` floats each in `partials`
+ * (observer.hip's partial layout; capacity >= 3 * dlmcq_conv2d_i8_observed_partials(N P Q, K) floats, else DLMCQ_ESCRATCH);
+ * dlmcq_minmax_finalize_f32 reduces them to what dlmcq_minmax_f32 gives for the tensor - max and min are exact, so bit for bit.
+ * `*partials_count` (written on the host before the call returns) is 0 when the dispatch hands the call to a kernel without the
+ * observing epilogue (the block-end pointwise kernel): observe the tensor with dlmcq_minmax_f32 then. */
+size_t dlmcq_conv2d_i8_observed_partials(int64_t M, int64_t K);
+int dlmcq_conv2d_i8_nhwc_fused_observed(const void* x, const int8_t* w, float* out, const float* bias, const int32_t* wsum,
+                                        const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N,
+                                        int64_t H, int64_t W, int64_t C, int64_t K, int64_t R, int64_t S, int32_t stride,
+                                        int32_t pad, int32_t dilation, int32_t x_is_unsigned, const float* residual,
+                                        int32_t relu, void* codes, const float* q_scale, const float* q_zero_point,
+                                        int32_t q_lo, int32_t q_hi, int32_t q_form, float q_ste_g, float* partials,
+                                        int64_t partials_capacity, int64_t* partials_count, dlmcq_stream_t stream);
 
 /* dlmcq_conv2d_i8_nhwc_fused for ASYMMETRIC per-output-channel weights (ops.py:129-136, unsigned `minmax_channel`:
  * w' = qw * s_w[k] + o_w[k], the offset being the channel minimum; BASELINE configs[4], W4A8): the convolution gains the

@@ -665,6 +665,38 @@ def test_eager_fused_calibrates_and_runs_like_the_model(name, family):
         assert torch.equal(twin(x * 0.7).view(torch.int32), got1.view(torch.int32))      # the wrappers themselves are untouched
 
 
+def test_eager_fused_speculates_on_integer_zero_points_and_recovers_when_wrong():
+    """Round 5: EagerFused lets freshly calibrated FSPTQ layers ASSUME an integer zero point (one host read per forward instead of one per
+    layer: ZeroPointSpeculation).  With post-ReLU pixels every assumption holds; with N(0, 1) pixels the first layer's zero point is the
+    (negative, non-integer) minimum - its guess is wrong, every layer behind it calibrated on garbage, and the forward must notice, re-arm
+    and run again: in both cases the scales and the output are exactly those of `model(x)`."""
+    import copy
+    import workloads as W
+    from dlmc.utils.fuse import EagerFused
+    from dlmc.utils.merge_bn import merge_bn
+    from dlmc.utils.quantize import quantize_model
+    cfg = {"weight": {"enable": True, "type": "minmax_channel", "args": {"n_bits": 8, "signed": True}},
+           "input": {"enable": True, "type": "minmax_tensor", "args": {"n_bits": 8, "signed": False}},
+           "exclude_layers": [], "override_options": []}
+    for pixels, held in (("halfnormal", True), ("normal", False)):
+        torch.manual_seed(5)
+        net = merge_bn(W.MODELS["resnet18"]().to(DEV).eval(), inplace=True, allow_missing=True)
+        quantize_model(net, cfg, None, "FSPTQ", int8_gemm=True)
+        twin = copy.deepcopy(net)
+        x = torch.randn(4, 3, 64, 64, device=DEV)
+        if pixels == "halfnormal":
+            x = torch.relu(x)
+        with torch.no_grad():
+            want = net(x)
+            fused = EagerFused(twin)
+            got = fused(x)
+        assert fused.speculation["layers"] >= 16 and fused.speculation["held"] is held, (pixels, fused.speculation)
+        sa, sb = net.state_dict(), twin.state_dict()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (pixels, k)
+        assert torch.equal(want.view(torch.int32), got.view(torch.int32)), pixels
+
+
 def test_eager_fused_keeps_its_promise_on_shortcuts_it_cannot_fuse():
     """EagerFused promises `y == model(x)`: a broadcast shortcut (not the layer's output shape) and an in-place add INTO the shortcut
     (`short += layer(x)`: the fused launch would not mutate `short`) must run layer, add and ReLU one by one - same bits, and the
@@ -707,3 +739,42 @@ def test_eager_fused_keeps_its_promise_on_shortcuts_it_cannot_fuse():
             assert torch.equal(g.view(torch.int32), w.view(torch.int32))
         for g, w in zip(fused(x * 0.5), net(x * 0.5)):
             assert torch.equal(g.view(torch.int32), w.view(torch.int32))
+
+
+@pytest.mark.parametrize("shape", [(6, 64, 20, 20, 256, True, True), (5, 128, 9, 13, 64, False, False), (3, 64, 7, 7, 1000, True, False)], ids=str)
+def test_observing_epilogue_gives_the_observer_s_min_and_max(shape):
+    """dlmcq_conv2d_i8_nhwc_fused_observed + dlmcq_minmax_finalize_f32 (round 5, the first batch): the (max, min) - and max |x|, and a NaN -
+    of the tiled kernel's fp32 output from its own epilogue equal dlmcq_minmax_f32 over the stored tensor bit for bit, and the scale / offset
+    derived from them equal observe_qparams's."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    from dlmc.quantization.scalar._wrapper import observe_minmax
+    n, c, h, w, k, relu, with_res = shape
+    g = torch.Generator(device=DEV).manual_seed(n + c + k)
+    codes = torch.randint(0, 256, (n, c, h, w), generator=g, device=DEV, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+    wq = torch.randint(-127, 128, (k, 1, 1, c), generator=g, device=DEV, dtype=torch.int8)
+    wsum = wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
+    s_w = (torch.rand(k, generator=g, device=DEV) * 4e-4 + 5e-5).contiguous()
+    bias = torch.randn(k, generator=g, device=DEV)
+    res = torch.randn((n, k, h, w), generator=g, device=DEV).contiguous(memory_format=torch.channels_last) if with_res else None
+    s_in = torch.full((1,), 0.021, device=DEV)
+    for poison in (None, float("nan"), float("inf")):
+        if poison is not None and res is None:
+            continue
+        if poison is not None:
+            res = res.clone()
+            res[n - 1, k - 1, h - 1, w - 1] = poison
+        out = K.conv2d_i8(codes, wq, wsum, bias, s_in, None, s_w, residual=res, relu=relu, observe=True)
+        hint = K.minmax_hint(out)
+        assert hint is not None and hint[1] >= 1
+        for mode in (N.MINMAX_MINMAX, N.MINMAX_NEGMIN, N.MINMAX_ABSMAX):
+            a, b = K.minmax_from_partials(*hint, mode=mode)
+            a0, b0 = K.minmax(out, mode=mode)
+            assert torch.equal(a.view(torch.int32), a0.view(torch.int32)), (poison, mode)
+            assert b is None or torch.equal(b.view(torch.int32), b0.view(torch.int32)), (poison, mode)
+        for signed in (False, True):
+            s1, o1 = observe_minmax(out, 8, signed, hint=hint)
+            s0, o0 = observe_minmax(out, 8, signed)
+            assert torch.equal(s1.view(torch.int32), s0.view(torch.int32)) and torch.equal(o1.view(torch.int32), o0.view(torch.int32)), (poison, signed)
+        out.add_(1.0)                                     # an in-place write: the hint no longer describes the tensor
+        assert K.minmax_hint(out) is None
