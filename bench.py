@@ -708,11 +708,12 @@ def main():
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded replicas)"},
         **({"first_batch": {"ms": round(first_batch_ms, 2), "images_per_s": round(args.batch * world / (first_batch_ms * 1e-3), 1),
                             "how": first_batch_how, "module_path_ms": round(first_batch_module_ms, 2),
-                            "what": "one forward with every observer on (min/max pass and all-reduce(MAX) per activation quantiser, "
-                                    "per-channel weight scales, one host read of the zero point per layer, then the layer); `how` = "
-                                    "EagerFused: layer + shortcut add + ReLU are one int8 launch wherever the layer is on the int8 route "
-                                    "(same scales and outputs as the module path, whose time is `module_path_ms`: there torch's ReLU / add "
-                                    "run between the layers); not part of `value`"}}
+                            "what": "one forward with every observer on (min/max and all-reduce(MAX) per activation quantiser, per-channel "
+                                    "weight scales, then the layer); `how` = EagerFused: layer + shortcut add + ReLU are one int8 launch wherever "
+                                    "the layer is on the int8 route, the consumer's min/max comes out of that launch's epilogue where the tiled "
+                                    "kernel ran (round 5: no second read of the tensor), and the zero points are checked with ONE host read per "
+                                    "forward (same scales and outputs as the module path, whose time is `module_path_ms`: torch's ReLU / add "
+                                    "between the layers, a min/max pass and a host read per layer); host-launch-bound; not part of `value`"}}
            if first_batch_ms is not None else {}),
         "roofline": main_roof,
         **({"roofline_second_kernel": second_roof} if second_roof else {}),

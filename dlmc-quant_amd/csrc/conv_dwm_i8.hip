@@ -150,11 +150,13 @@ __global__ __launch_bounds__(256, 3) void conv_dwm_i8_kernel(DwmArgs a, ConvEpi 
   auto request = [&](int t, int bf) { issue_halo(t < a.ntiles ? t : a.ntiles - 1, bf); };
 #pragma unroll
   for (int d = 0; d < NHB - 1; ++d) request(tile + d * ngroups, d);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NHB - 2) * HPW) : "memory");      // the first tile's halo (the loop's wait counts two stores that do not exist yet)
+  constexpr int NSTO = DWM_TP / 64;     // 16-byte stores a thread issues per tile (round 5: the wait below is derived from it - it used to say "+ 2"
+                                        // for the 128-position tiles of an earlier build and was stricter than meant at 192: ADVICE r4)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NHB - 2) * HPW) : "memory");      // the first tile's halo (the loop's wait counts stores that do not exist yet)
   for (; tile < a.ntiles; tile += ngroups, buf = (buf + 1 == NHB ? 0 : buf + 1)) {
-    // this tile's halo has landed; the halos of the next NHB - 2 tiles and the previous tile's two stores may still be in flight
+    // this tile's halo has landed; the halos of the next NHB - 2 tiles and the previous tile's NSTO stores may still be in flight
     // (behind the prologue there are no stores yet: the wait is then stricter than it has to be)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NHB - 2) * HPW + 2) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NHB - 2) * HPW + NSTO) : "memory");
     request(tile + (NHB - 1) * ngroups, buf == 0 ? NHB - 1 : buf - 1);
     const int8_t* const hb = lds + buf * HALO;
     // two blocks of 32 positions at a time: their accumulation chains are independent, so one block's MFMA issues while the
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 3) void conv_dwm_i8_kernel(DwmArgs a, ConvEpi 
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the tile's codes are staged (a position's 64 bytes come from four waves)
     // row-major out of the stage: 4 threads x 16 bytes per position; frame positions with x = W or y = H, or beyond the batch, are
-    // junk: their store goes to an offset beyond the tensor (every thread issues its two stores: the counted wait above)
+    // junk: their store goes to an offset beyond the tensor (every thread issues its NSTO stores: the counted wait above)
     const uint32_t q0 = (uint32_t)tile * DWM_TP;
 #pragma unroll
     for (int it = 0; it < DWM_TP / 64; ++it) {
