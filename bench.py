@@ -232,31 +232,38 @@ def family_roofline(tag, f):
     return {"bound": b, "achieved": r[b]["achieved"], "peak": r[b]["peak"], "unit": r[b]["unit"], "frac": r[b]["frac"], "traffic": None, **r}
 
 
-def pmc_traffic(kernel_substr, launches, algorithmic, pattern="*pmc_bench_fused_plan*.json"):
+def pmc_traffic(kernel_substr, launches, algorithmic, pattern="*pmc_bench_fused_plan*.json", directory=None):
     """HBM bytes per launch of a kernel family from the committed PMC passes of this same command, run with --no-other-configs
     (profiles/*pmc_bench*.json, made by tools/pmc_summary.py --tail; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     16-byte-per-lane streaming reads on gfx950).  A TAIL entry is used only if it describes THIS step's launches: its dispatch
     count must equal the family's launches per step, and its bytes must not be below 0.9 x the family's algorithmic bytes (round 4's
     file held the side networks' dispatches for two families: less traffic than the layers' own operands - refused now, with the reason).
+    Only the NEWEST file (highest round) that knows the kernel is asked: an older round's passes describe an older build.
     Returns (bytes, file, reason-if-refused)."""
     import glob
     why = f"no profiles/{pattern} with a TAIL entry for this kernel"
-    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pattern)), reverse=True):
+    directory = directory or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for path in sorted(glob.glob(os.path.join(directory, pattern)), reverse=True):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        for k, v in d.items():
+        known = False
+        for k, v in d.items():          # (a file may hold several tails of a kernel - different dispatch counts: the step's is the one that counts)
             if k.startswith("TAIL") and kernel_substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                known = True
                 got = int((2 * v["FETCH_SIZE"]["mean_KiB"] + v["WRITE_SIZE"]["mean_KiB"]) * 1024)
                 n = (v["FETCH_SIZE"]["dispatches"], v["WRITE_SIZE"]["dispatches"])
                 if n != (launches, launches):
-                    why = f"{os.path.basename(path)}: TAIL holds {n} dispatches, the step has {launches} launches of this kernel"
+                    if "below 0.9" not in why:
+                        why = f"{os.path.basename(path)}: TAIL holds {n} dispatches, the step has {launches} launches of this kernel"
                 elif algorithmic and got < 0.9 * algorithmic:
                     why = (f"{os.path.basename(path)}: TAIL reads {got} B per launch, below 0.9 x the {algorithmic} algorithmic bytes - "
                            "not this step's launches; not reported")
                 else:
                     return got, os.path.basename(path), None
+        if known:
+            return None, None, why
     return None, None, why
 
 

@@ -315,7 +315,10 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
         }
       }
 #endif
-      const int lo = fo[g] + n * cstep;
+      int lo = fo[g] + n * cstep;
+#ifdef DLMCQ_LAB
+      if (a.lab & 0x2000) lo &= 0xffff;
+#endif
       bload16(res[P][g], lo, r_res);
     }
   };
@@ -430,7 +433,13 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
         }
         if constexpr (!DUALH) y[k] = y[k] + res[P][g];
         if (relu1 && (FL < 0 || out1)) y[k] = relu4_nan(y[k]);      // (plain quantiser: only the fp32 output needs the rectified value)
+#ifdef DLMCQ_LAB
+        // timing only (round 5): 0x1000 - the fp32 stores land in a 64 KB window of the output (they stay in L2: what do the STORE INSTRUCTIONS cost
+        // without their HBM traffic?); 0x2000 - the same for the shortcut loads (below)
+        if (out1) bstore16(y[k], (a.lab & 0x1000) ? ((fo[g] + n * cstep) & 0xffff) : fo[g] + n * cstep, r_out);
+#else
         if (out1) bstore16(y[k], fo[g] + n * cstep, r_out);
+#endif
       }
       uint32_t c[GP];
       if constexpr (FL >= 0) {

@@ -263,3 +263,25 @@ def test_pointwise_kernel_listing_leaves_in_flight_fragments_alone():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "lint_pw.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "residual-block kernels checked, 0 problem(s)" in r.stdout, r.stdout
+
+
+def test_bench_refuses_counter_tails_that_are_not_the_step_s_launches(tmp_path):
+    """bench.py:pmc_traffic (round 5; VERDICT r4: a TAIL that held the side networks' dispatches fed the headline's roofline objects): a tail
+    is used only when its dispatch count is the step's launch count and its bytes are not below 0.9 x the algorithmic bytes; only the newest
+    round's file is asked; a refusal carries its reason."""
+    import json
+    import bench
+    tail = lambda n, f, w: {"FETCH_SIZE": {"dispatches": n, "mean_KiB": f}, "WRITE_SIZE": {"dispatches": n, "mean_KiB": w}}
+    (tmp_path / "r04_pmc_bench_fused_plan.json").write_text(json.dumps({"TAIL last 16 dispatches of *conv3x3_halo_i8_kernel*": tail(16, 50000.0, 30000.0)}))
+    (tmp_path / "r05_pmc_bench_fused_plan.json").write_text(json.dumps({
+        "TAIL last 16 dispatches of *conv3x3_halo_i8_kernel*": tail(16, 17414.82, 28224.0),        # 64.6 MB: RepVGG's layers, not ResNet-50's 105.9 MB
+        "TAIL last 11 dispatches of *conv_chain_i8_kernel*": tail(11, 366460.9, 780499.34),
+        "TAIL last 6 dispatches of *conv_i8_mfma_kernel*": tail(6, 10651.0, 127565.09)}))
+    got, src, why = bench.pmc_traffic("conv_chain_i8_kernel", 11, 1546270000, directory=str(tmp_path))
+    assert src == "r05_pmc_bench_fused_plan.json" and why is None and abs(got / 1546270000 - 1.002) < 0.01
+    got, src, why = bench.pmc_traffic("conv3x3_halo_i8_kernel", 16, 105900000, directory=str(tmp_path))
+    assert got is None and src is None and "below 0.9" in why and "r05" in why            # (and NOT the older round's plausible-looking entry)
+    got, src, why = bench.pmc_traffic("conv_i8_mfma_kernel", 4, 0, directory=str(tmp_path))
+    assert got is None and "TAIL holds (6, 6) dispatches" in why
+    got, src, why = bench.pmc_traffic("conv_pwr_i8_kernel", 4, 1, directory=str(tmp_path))
+    assert got is None and "no profiles" in why

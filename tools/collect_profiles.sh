@@ -21,10 +21,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- pyt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-other-configs --no-fake-quant-leg > "$OUT/fetch.log" 2>&1 || echo "fetch pass failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o p -- python3 "$B" --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-other-configs --no-fake-quant-leg > "$OUT/write.log" 2>&1 || echo "write pass failed"
 cd "$GRAFT_REPO_ROOT"
-python3 tools/pmc_summary.py --tail conv_chain_i8_kernel 11 --tail conv_i8_mfma_kernel 6 --tail conv3x3_halo_i8_kernel 16 --tail conv_pwr_i8_kernel 4 --tail conv_stem_pool7_i8_kernel 1 --tail quantize_pad_nhwc4 1 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
+# (several tails per kernel where the per-step launch count depends on the dispatch: bench.py takes the one whose count is its step's)
+python3 tools/pmc_summary.py --tail conv_chain_i8_kernel 11 --tail conv_i8_mfma_kernel 4 --tail conv_i8_mfma_kernel 5 --tail conv_i8_mfma_kernel 6 --tail conv3x3_halo_i8_kernel 16 --tail conv_pwr_i8_kernel 4 --tail conv_pw_i8_kernel 3 --tail conv_stem_pool7_i8_kernel 1 --tail quantize_pad_nhwc4 1 "$OUT/fetch" "$OUT/write" > "$OUT/pmc_bench_fused_plan.json" || true
 # the side networks' own passes (their rooflines' traffic): RepVGG-A1's 21 halo-kernel layers, MobileOne-S1's depthwise / pointwise families
 cd /tmp
-for mk in "repvgg_a1 conv3x3_halo_i8_kernel:21" "mobileone_s1 conv_dwm_i8_kernel:17,conv_pw_i8_kernel:21"; do
+for mk in "repvgg_a1 conv3x3_halo_i8_kernel:19,conv3x3_halo_i8_kernel:20,conv3x3_halo_i8_kernel:21" "mobileone_s1 conv_dwm_i8_kernel:17,conv_pw_i8_kernel:20,conv_pw_i8_kernel:21,conv_dw3_i8_kernel:4"; do
   set -- $mk; M=$1; TAILS=""
   for kv in $(echo $2 | tr ',' ' '); do TAILS="$TAILS --tail ${kv%%:*} ${kv##*:}"; done
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_$M" -o p -- python3 "$B" --model $M --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/fetch_$M.log" 2>&1 || echo "fetch pass $M failed"
