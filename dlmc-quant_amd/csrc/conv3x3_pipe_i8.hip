@@ -47,6 +47,16 @@ struct PipeGeom {
 
 constexpr int PIPE_KMAX = 512;     // output channels the constant table in LDS holds
 
+// -DDLMCQ_PIPE_STAMP (A/B library only, tools/halo_pipe_lab.sh): wave 0 of workgroup 0 records the shader clock at every K step of its first two
+// tiles, and the shader clock + the 100 MHz constant clock around its whole life (their quotient = the clock the chip holds under this kernel)
+#ifdef DLMCQ_PIPE_STAMP
+__device__ unsigned long long g_pipe_stamps[256];
+__device__ unsigned long long g_pipe_wg[1024];       // per workgroup: start, end in 100 MHz ticks (s_memrealtime: one clock for the whole chip)
+#define PIPE_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 250) g_pipe_stamps[(i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PIPE_STAMP(i) do { } while (0)
+#endif
+
 template <int NCH, bool XS>
 __global__ __launch_bounds__(512, 2) void conv3x3_pipe_i8_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w, const float* __restrict__ bias, const int32_t* __restrict__ wsum,
@@ -343,6 +353,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_i8_kernel(
   read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, halo, wfA, pfA);
   store_rows(0u, 0, false);        // (NST stores that go nowhere: the queue every tile's first waits count on)
 
+#ifdef DLMCQ_PIPE_STAMP
+  int stamp_i = 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_pipe_stamps[0] = __builtin_readcyclecounter();
+    g_pipe_stamps[1] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (threadIdx.x == 0 && blockIdx.x < 512) g_pipe_wg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
   for (;;) {
     const bool has_next = vb + G < g.ntiles;
     uint32_t q0N = 0;
@@ -360,6 +378,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_i8_kernel(
       static_for<9>([&](auto t_c) {
         constexpr int t = decltype(t_c)::value;
         constexpr int U = t % NBUF;
+#ifdef DLMCQ_PIPE_STAMP
+        PIPE_STAMP(stamp_i);
+        ++stamp_i;
+#endif
         // phase 0: this half-step's LDS reads (the other fragment set, the next quad's constants) in FRONT of its MFMAs
         read_frags(std::integral_constant<int, U>{}, t_c, std::integral_constant<int, 1>{}, hcur, wfB, pfB);
         quads_prefetch(std::integral_constant<int, 2 * t>{});
@@ -432,6 +454,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_i8_kernel(
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   store_rows(q0E, n0E, true);
+#ifdef DLMCQ_PIPE_STAMP
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_pipe_stamps[2] = __builtin_readcyclecounter();
+    g_pipe_stamps[3] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (threadIdx.x == 0 && blockIdx.x < 512) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g_pipe_wg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 template <int NCH>
@@ -445,6 +477,16 @@ static int conv3x3_pipe_go(const int8_t* x, const int8_t* w, const float* bias, 
   return launch_status();
 }
 
+#ifdef DLMCQ_PIPE_STAMP
+}  // namespace dlmcq
+extern "C" int dlmcq_x_pipe_stamps(unsigned long long* host256) {
+  return (int)hipMemcpyFromSymbol(host256, HIP_SYMBOL(dlmcq::g_pipe_stamps), 256 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int dlmcq_x_pipe_wg(unsigned long long* host1024) {
+  return (int)hipMemcpyFromSymbol(host1024, HIP_SYMBOL(dlmcq::g_pipe_wg), 1024 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+namespace dlmcq {
+#endif
 bool conv3x3_pipe_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int32_t stride, const ConvEpi& ep, int cus) {
   if (stride != 1 || !(C == 128 || C == 256 || C == 512) || K % 128 != 0 || K > PIPE_KMAX || !epi_plain(ep)) return false;
   if (W + 1 > 62) return false;                                                   // six halo pieces per wave
