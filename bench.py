@@ -451,6 +451,8 @@ def main():
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
                     help="default model only: skip the short RepVGG-A1 b512 / MobileOne-S1 b1024 runs reported under `other_configs`")
     ap.add_argument("--other-steps", type=int, default=50, help="timed steps of each `other_configs` run (10 warm-up steps)")
+    ap.add_argument("--row-major-blocks", action="store_true",
+                    help="A/B: keep the fp32 block tensors between chain kernels row-major (fuse_inference(block_layout=False)) instead of chunk-major")
     ap.add_argument("--no-fake-quant-leg", dest="fq_leg", action="store_false",
                     help="skip `roofline_fake_quant_resnet50`: three forwards of the same model in `--conv fp32 --plan modules` form behind the "
                          "headline region (the stand-alone fake-quant kernels' own roofline on the whole network)")
@@ -548,7 +550,7 @@ def main():
                 first_batch_ms, first_batch_how = (time.perf_counter() - t0) * 1e3, "EagerFused"
         if args.fused:
             from dlmc.utils.fuse import fuse_inference
-            model = fuse_inference(model)        # scales are frozen from here on (BASELINE configs[2]: steady state)
+            model = fuse_inference(model, block_layout=not args.row_major_blocks)        # scales are frozen from here on (BASELINE configs[2]: steady state)
         single = model
         if args.fused and args.streams > 1 and not w4a8:     # (QBase plans - grad_scale depends on the elements per call - are not split)
             from dlmc.utils.fuse import StreamedPlan

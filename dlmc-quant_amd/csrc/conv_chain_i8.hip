@@ -54,6 +54,9 @@ struct ChainArgs {
   uint8_t* codes2;         // [M][KB]
   int w3_row, w3_chunk;    // byte strides of w3: from output channel to output channel, from 64-column chunk to chunk (KRSC: KD, 64; chunk-major: 64, KB * 64)
   int M, KD, rows_per_tile;
+  // layout of the two fp32 tensors - f_: the shortcut read, o_: the block output written - as fp32 elements from row to row / bytes
+  // from 64-channel chunk to chunk.  Row-major [M][KD]: KD, 256.  Chunk-major [KD / 64][M][64] (DLMCQ_FP32_*_CHUNK_MAJOR): 64, M * 256
+  int f_rowq, f_cstep, o_rowq, o_cstep;
   int lab;                     // lab builds: 1 = no shortcut loads (timing only)
   unsigned long long* trace;   // lab builds: 64 clock-stamp slots per workgroup (null: none)
 };
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int lr = wr * 32 + 8 * g + rsel;
-    fo[g] = lr < rows_here ? (int)(((row0 + lr) * a.KD + wc * 32 + q4 * 4) * 4) : CH_BIG;
+    fo[g] = lr < rows_here ? (int)(((row0 + lr) * a.f_rowq + wc * 32 + q4 * 4) * 4) : CH_BIG;
 #ifdef DLMCQ_LAB
     if (a.lab & 4) {   // timing only: the access pattern a 16 x 16 x 64 accumulator layout would have - 16 rows x 64 bytes per instruction
       const int lr2 = wr * 32 + 16 * (g >> 1) + 2 * (4 * hsel + b4) + (q4 >> 2);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     }
 #endif
   }
-  int cstep = 256;       // byte distance between a row's consecutive 64-channel chunks
+  int cstep = a.f_cstep; // byte distance between a row's consecutive 64-channel chunks
 #ifdef DLMCQ_LAB
   if (a.lab & 64) {      // timing only: the fp32 tensors in 64 x 64 blocks (every chunk of a tile one contiguous 16 KB)
     cstep = 64 * 256;
@@ -246,6 +249,24 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     }
   }
 #endif
+  // the output's offsets: the shortcut's, unless the two tensors differ in layout (one row-major, one chunk-major: a chain between a
+  // kernel that does not know the chunk-major form and one that does).  The instantiation that sits at its register limit has no room
+  // for a second set: chain_launch refuses mixed layouts for it.
+  constexpr bool MIXED_OK = !DUALH && !(C1 == 128 && KB == 128);
+  int fo2[MIXED_OK ? 4 : 1];
+  const int cstep2 = a.o_cstep;
+  if constexpr (MIXED_OK) {
+    const bool same = a.o_rowq == a.f_rowq;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int lr = wr * 32 + 8 * g + rsel;
+      fo2[g] = same ? fo[g] : (lr < rows_here ? (int)(((row0 + lr) * a.o_rowq + wc * 32 + q4 * 4) * 4) : CH_BIG);
+    }
+  }
+  auto out_off = [&](int g, int n) {
+    if constexpr (MIXED_OK) return fo2[g] + n * cstep2;
+    else return fo[g] + n * cstep;
+  };
   // transposition stage: row 4 hsel + j of a group holds this lane's register 4 g + j at column l31; a lane reads back row
   // 4 hsel + b4, columns 4 q4 .. + 3; 4-column slot c of row r sits at slot c ^ (r & 7)
   int tw[4];
@@ -436,9 +457,9 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 #ifdef DLMCQ_LAB
         // timing only (round 5): 0x1000 - the fp32 stores land in a 64 KB window of the output (they stay in L2: what do the STORE INSTRUCTIONS cost
         // without their HBM traffic?); 0x2000 - the same for the shortcut loads (below)
-        if (out1) bstore16(y[k], (a.lab & 0x1000) ? ((fo[g] + n * cstep) & 0xffff) : fo[g] + n * cstep, r_out);
+        if (out1) bstore16(y[k], (a.lab & 0x1000) ? (out_off(g, n) & 0xffff) : out_off(g, n), r_out);
 #else
-        if (out1) bstore16(y[k], fo[g] + n * cstep, r_out);
+        if (out1) bstore16(y[k], out_off(g, n), r_out);
 #endif
       }
       uint32_t c[GP];
@@ -536,8 +557,12 @@ static int chain_launch(ChainArgs& a, int64_t M, int64_t C, int64_t K, int64_t C
                         int32_t relu2, void* codes2, const float* q2_scale, const float* q2_zero_point, int32_t q2_lo, int32_t q2_hi,
                         int32_t q2_form, float q2_ste_g, int32_t rows_per_tile, dlmcq_stream_t stream) {
   if (q_lo != 0 || q_hi != 255) return DLMCQ_EINVAL;   // GEMM 2 reads the codes as uint8 (shift 128)
-  const bool w3cm = (q2_form & DLMCQ_W2_CHUNK_MAJOR) != 0;
-  q2_form &= ~DLMCQ_W2_CHUNK_MAJOR;
+  const bool w3cm = (q2_form & DLMCQ_W2_CHUNK_MAJOR) != 0, ocm = (q2_form & DLMCQ_FP32_OUT_CHUNK_MAJOR) != 0;
+  // (a call without a shortcut tensor - the convolution-shortcut form - or without an output has ONE fp32 tensor: its layout is the call's)
+  const bool icm = (C2 == 0 && a.residual) ? (q2_form & DLMCQ_FP32_IN_CHUNK_MAJOR) != 0 : ocm;
+  const bool ocm2 = a.out ? ocm : icm;
+  q2_form &= ~(DLMCQ_W2_CHUNK_MAJOR | DLMCQ_FP32_IN_CHUNK_MAJOR | DLMCQ_FP32_OUT_CHUNK_MAJOR);
+  if (icm != ocm2 && C2 == 0 && C == 128 && K2 == 128) return DLMCQ_EINVAL;   // (no registers for two offset sets there: conv_chain_i8_kernel)
   a.w3_row = w3cm ? 64 : (int)K;
   a.w3_chunk = w3cm ? (int)K2 * 64 : 64;
   ConvEpi ep1{}, ep2{};
@@ -546,6 +571,10 @@ static int chain_launch(ChainArgs& a, int64_t M, int64_t C, int64_t K, int64_t C
     return DLMCQ_EINVAL;
   if (M * K * 4 > (int64_t)CH_BIG) return DLMCQ_ERANGE;   // 32-bit buffer offsets
   a.M = (int)M; a.KD = (int)K;
+  a.f_rowq = icm ? 64 : (int)K;
+  a.f_cstep = icm ? (int)M * 256 : 256;
+  a.o_rowq = ocm2 ? 64 : (int)K;
+  a.o_cstep = ocm2 ? (int)M * 256 : 256;
 #ifdef DLMCQ_LAB
   a.trace = g_chain_trace;
   a.lab = g_chain_lab;

@@ -29,6 +29,8 @@ EMIT_SHIFT128 = 0x100    # DLMCQ_EMIT_SHIFT128: OR-able into q_form (include/dlm
 W2_CHUNK_MAJOR = 0x200   # DLMCQ_W2_CHUNK_MAJOR: OR-able into the chain entry points' last quantiser form
 FORCE_TILED = 0x400      # DLMCQ_FORCE_TILED: OR-able into q_form of conv2d_i8_nhwc_fused / _asym / _dual / conv2d_dw_i8_nhwc: the family's generic kernel
 ROUTE_ONLY = 0x800       # DLMCQ_ROUTE_ONLY: launch nothing, return which kernel the dispatch picks (ROUTE_*)
+FP32_IN_CHUNK_MAJOR = 0x2000   # DLMCQ_FP32_IN_CHUNK_MAJOR: a chain call's fp32 shortcut is [K / 64][M][64] (kernels.ChunkMajor)
+FP32_OUT_CHUNK_MAJOR = 0x4000  # DLMCQ_FP32_OUT_CHUNK_MAJOR: ... and / or its fp32 block output
 PIPELINED = 0x1000       # DLMCQ_PIPELINED (opt-in): the persistent, software-pipelined halo-tile 3x3 kernel where it applies
 ROUTE_TILED, ROUTE_HALO3X3, ROUTE_PW, ROUTE_PWR, ROUTE_DW, ROUTE_DWM, ROUTE_HALO3X3_PIPE = 1, 2, 3, 4, 5, 6, 7
 ROUTE_TAG = {ROUTE_TILED: "conv_i8", ROUTE_HALO3X3: "conv3x3_halo", ROUTE_PW: "conv_pw", ROUTE_PWR: "conv_pwr", ROUTE_DW: "conv_dw",

@@ -694,6 +694,7 @@ def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True, force_tiled=False
 
 
 CHAIN_SHAPES = {(64, 64), (64, 128), (128, 128), (128, 256), (256, 256)}   # (C, K2) pairs dlmcq_conv2d_i8_nhwc_chain is built for
+CHAIN_ONE_LAYOUT = {(128, 128)}    # ... and those whose two fp32 tensors must share one layout (row-major or ChunkMajor, not one of each)
 
 
 def chain_supported(c, k, k2, m):
@@ -710,6 +711,46 @@ def chunk_major(wq):
     return wq.reshape(k2, k // 64, 64).permute(1, 0, 2).contiguous()
 
 
+class ChunkMajor:
+    """An fp32 block tensor [N, K, H, W] kept CHUNK-MAJOR between two kernels that walk it chunk by chunk (DLMCQ_FP32_CHUNK_MAJOR):
+    `buf` is [K / 64, N * H * W, 64] - every 64-channel chunk one plane of M rows x 256 bytes - so that the pieces neighbouring workgroups
+    touch at the same time are neighbours in memory (HBM serves that at 5.9 - 6.0 TB/s, the row-major tensor's 256-byte pieces K * 4 bytes
+    apart at 4.6 - 5.8: tools/probes/stream_pattern_probe.hip).  Deliberately NOT a tensor: only the chain / block-end wrappers below take
+    it, anything else fails loudly; `.to_nhwc()` gives the ordinary channels_last tensor (same values)."""
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape = buf, tuple(shape)
+        self.dtype, self.device = buf.dtype, buf.device
+
+    @staticmethod
+    def empty(n, k, h, w, device):
+        if k % 64:
+            raise ValueError("ChunkMajor: K % 64 = 0")
+        return ChunkMajor(torch.empty((k // 64, n * h * w, 64), dtype=torch.float32, device=device), (n, k, h, w))
+
+    @staticmethod
+    def from_nhwc(t):
+        n, k, h, w = t.shape
+        if k % 64 or t.dtype != torch.float32:
+            raise ValueError("ChunkMajor: an fp32 tensor with K % 64 = 0")
+        rows = t.permute(0, 2, 3, 1).reshape(n * h * w, k // 64, 64)
+        return ChunkMajor(rows.permute(1, 0, 2).contiguous(), (n, k, h, w))
+
+    def to_nhwc(self):
+        n, k, h, w = self.shape
+        rows = self.buf.permute(1, 0, 2).reshape(n, h, w, k)
+        return rows.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+
+    def window(self, n, p0, p1, q0, q1):
+        """[1, K, p1 - p0, q1 - q0] of image n as an ordinary tensor (tests and tools look at windows of full-size tensors)."""
+        nn, k, h, w = self.shape
+        rows = self.buf.view(k // 64, nn, h, w, 64)[:, n, p0:p1, q0:q1, :]
+        return rows.permute(1, 2, 0, 3).reshape(1, p1 - p0, q1 - q0, k).permute(0, 3, 1, 2).contiguous()
+
+    def record_stream(self, s):
+        self.buf.record_stream(s)
+
+
 def _second_weights(b):
     """(pointer tensor, form flag) of a chain kernel's second layer: its chunk-major copy when the operand dict carries one."""
     wc = b.get("wq_chunk")
@@ -722,13 +763,20 @@ def _second_weights(b):
 
 
 def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_codes=False, relu2=True, emit2=None,
-                    rows_per_tile=0):
+                    rows_per_tile=0, out_chunk_major=False):
     """A block's last 1x1 convolution (+ residual, ReLU, the consumer's quantiser `emit`) and the next block's first 1x1
     convolution (+ ReLU, its consumer's quantiser `emit2`) in one kernel (dlmcq_conv2d_i8_nhwc_chain).  `a`: dict with
     codes, wq, wsum, bias, in_scale, in_zp, w_scale of the first layer; `b`: wq, wsum, bias, w_scale of the second (its
-    input quantiser is `emit`).  Returns (out or None, codes or None, codes2)."""
+    input quantiser is `emit`).  Returns (out or None, codes or None, codes2).  `residual` may be a ChunkMajor; `out_chunk_major`
+    asks for the fp32 output as one (the 128 -> K -> 128 instantiation keeps both fp32 tensors of a call in ONE layout: there a
+    residual in the other layout is converted first - a copy; plans avoid it)."""
     _no_shift(emit, "conv2d_i8_chain")
     c = a["codes"]
+    icm, ocm = isinstance(residual, ChunkMajor), bool(out_chunk_major) and want_out
+    if want_out and icm != ocm and (c.shape[1], b["wq"].shape[0]) in CHAIN_ONE_LAYOUT:
+        residual = residual.to_nhwc() if icm else ChunkMajor.from_nhwc(residual)
+        icm = ocm
+    res_cm, residual = (residual, residual.buf) if icm else (None, residual)
     N.require_gpu(c, a["wq"], b["wq"], residual)
     if not c.is_contiguous(memory_format=torch.channels_last):
         c = c.contiguous(memory_format=torch.channels_last)
@@ -737,15 +785,16 @@ def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_co
     K2, R2, S2, C2 = b["wq"].shape
     if (R, S, R2, S2) != (1, 1, 1, 1) or C2 != K_ or emit is None or emit2 is None:
         raise ValueError("conv2d_i8_chain: two 1x1 convolutions, the second reading the first's codes")
-    if tuple(residual.shape) != (n, K_, h, w_) or residual.dtype != torch.float32:
+    if tuple(res_cm.shape if icm else residual.shape) != (n, K_, h, w_) or residual.dtype != torch.float32:
         raise ValueError("conv2d_i8_chain: residual must be fp32 of the first output's shape")
-    if not residual.is_contiguous(memory_format=torch.channels_last):
+    if not icm and not residual.is_contiguous(memory_format=torch.channels_last):
         residual = residual.contiguous(memory_format=torch.channels_last)
     m = n * h * w_
 
     def alloc(k, dtype):
         return torch.empty((n, k, h, w_), dtype=dtype, device=c.device, memory_format=torch.channels_last)
-    out = alloc(K_, torch.float32) if want_out else None
+    out = (ChunkMajor.empty(n, K_, h, w_, c.device) if ocm else alloc(K_, torch.float32)) if want_out else None
+    out_t = out.buf if ocm else out
     codes = alloc(K_, emit.dtype) if want_codes else None
     codes2 = alloc(K2, emit2.dtype)
 
@@ -762,10 +811,11 @@ def conv2d_i8_chain(a, b, residual, relu=True, emit=None, want_out=True, want_co
     nbytes = c.numel() + a["wq"].numel() + b["wq"].numel() + m * K_ * (4 + 4 * want_out + want_codes) + m * K2
     w2t, w2flag = _second_weights(b)
     PROFILE.launch("conv_chain", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_chain(
-        N.ptr(c), N.ptr(a["wq"]), N.ptr(out), N.ptr(b1), N.ptr(a["wsum"]), N.ptr(si), N.ptr(zp), N.ptr(ws1), m, ch, K_,
+        N.ptr(c), N.ptr(a["wq"]), N.ptr(out_t), N.ptr(b1), N.ptr(a["wsum"]), N.ptr(si), N.ptr(zp), N.ptr(ws1), m, ch, K_,
         int(c.dtype == torch.uint8), N.ptr(residual), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi,
         emit.form, emit.g, N.ptr(w2t), N.ptr(b2), N.ptr(b["wsum"]), N.ptr(ws2), K2, int(bool(relu2)), N.ptr(codes2),
-        N.ptr(qs2), N.ptr(qz2), emit2.lo, emit2.hi, emit2.form_arg | w2flag, emit2.g, int(rows_per_tile), N.stream_ptr())),
+        N.ptr(qs2), N.ptr(qz2), emit2.lo, emit2.hi, emit2.form_arg | w2flag | (N.FP32_IN_CHUNK_MAJOR if icm else 0) | (N.FP32_OUT_CHUNK_MAJOR if ocm else 0), emit2.g,
+        int(rows_per_tile), N.stream_ptr())),
         2 * m * K_ * (ch + K2))
     return out, codes, codes2
 
@@ -777,7 +827,8 @@ def dual_chain_supported(c, c2, k, k3, m):
     return (c, c2, k3) in DUAL_CHAIN_SHAPES and k % 64 == 0 and m * k * 4 <= 0x7fff0000
 
 
-def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_codes=False, relu3=True, emit3=None, rows_per_tile=0):
+def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_codes=False, relu3=True, emit3=None, rows_per_tile=0,
+                         out_chunk_major=False):
     """conv1x1(a) + conv1x1(b, strided) (+ ReLU, the consumer's quantiser `emit`) and the next 1x1 convolution `c3` on the
     codes, in one kernel (dlmcq_conv2d_i8_nhwc_dual_chain).  `a`, `b`: operand dicts as for conv2d_i8_dual (`b` may carry a
     stride); `c3`: wq, wsum, bias, w_scale.  Returns (out or None, codes or None, codes3)."""
@@ -799,7 +850,9 @@ def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_cod
 
     def alloc(k, dtype):
         return torch.empty((n, k, h, w_), dtype=dtype, device=ca.device, memory_format=torch.channels_last)
-    out = alloc(K_, torch.float32) if want_out else None
+    fcm = bool(out_chunk_major) and want_out
+    out = (ChunkMajor.empty(n, K_, h, w_, ca.device) if fcm else alloc(K_, torch.float32)) if want_out else None
+    out_t = out.buf if fcm else out
     codes = alloc(K_, emit.dtype) if want_codes else None
     codes3 = alloc(K3, emit3.dtype)
 
@@ -821,11 +874,11 @@ def conv2d_i8_dual_chain(a, b, c3, relu=True, emit=None, want_out=True, want_cod
         m * K_ * (4 * want_out + want_codes) + m * K3
     w3t, w3flag = _second_weights(c3)
     PROFILE.launch("conv_chain", nbytes, lambda: N.check(N.lib.dlmcq_conv2d_i8_nhwc_dual_chain(
-        N.ptr(ca), N.ptr(a["wq"]), N.ptr(out), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa), n, h, w_, ch, K_,
+        N.ptr(ca), N.ptr(a["wq"]), N.ptr(out_t), N.ptr(ba), N.ptr(a["wsum"]), N.ptr(sia), N.ptr(zpa), N.ptr(wsa), n, h, w_, ch, K_,
         int(ca.dtype == torch.uint8), N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2,
         ch2, st2, int(cb.dtype == torch.uint8), int(bool(relu)), N.ptr(codes), N.ptr(qs), N.ptr(qz), emit.lo, emit.hi, emit.form, emit.g,
         N.ptr(w3t), N.ptr(b3), N.ptr(c3["wsum"]), N.ptr(ws3), K3, int(bool(relu3)), N.ptr(codes3), N.ptr(qs3), N.ptr(qz3), emit3.lo,
-        emit3.hi, emit3.form_arg | w3flag, emit3.g, int(rows_per_tile), N.stream_ptr())),
+        emit3.hi, emit3.form_arg | w3flag | (N.FP32_OUT_CHUNK_MAJOR if fcm else 0), emit3.g, int(rows_per_tile), N.stream_ptr())),
         2 * m * K_ * (ch + ch2 + K3))
     return out, codes, codes3
 

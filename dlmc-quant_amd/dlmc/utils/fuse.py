@@ -385,6 +385,7 @@ class ChainInt8Layer(nn.Module):
         self.a, self.b, self.want_codes, self.short, self.main = a, b, bool(want_codes), short, (main if main is not None else a)
         self.swapped = short is not None and self.main is not a       # main reads the plan node's SECOND input
         self._w2cm = None      # the second layer's weight codes chunk-major (K.chunk_major), made at the first forward
+        self.out_cm = False    # the fp32 block output as a K.ChunkMajor (set by _block_layout_pass where only chain kernels read it)
 
     def forward(self, x, y):
         a, b, sc, mn = self.a, self.b, self.short, self.main
@@ -397,9 +398,12 @@ class ChainInt8Layer(nn.Module):
             if self._w2cm is None or self._w2cm.device != b.wq.device:
                 self._w2cm = K.chunk_major(b.wq)  # the plan's weights are frozen: made once
             nxt["wq_chunk"] = self._w2cm
-        kw = dict(relu=a.relu, emit=a._emit_for(n, a.k, h, w), want_out=a.want_out, want_codes=self.want_codes, emit2=b._emit_for(n, b.k, h, w))
+        kw = dict(relu=a.relu, emit=a._emit_for(n, a.k, h, w), want_out=a.want_out, want_codes=self.want_codes, emit2=b._emit_for(n, b.k, h, w),
+                  out_chunk_major=self.out_cm)
         if sc is None:
             if not K.chain_supported(c, a.k, b.k, n * h * w):
+                if isinstance(y, K.ChunkMajor):      # (the plan nodes one after the other know row-major tensors only)
+                    y = y.to_nhwc()
                 out, mid = a(x, y)
                 return out, (mid if self.want_codes else None), b(mid)[1]
             oa = dict(codes=codes, wq=a.wq, wsum=a.wsum, bias=a._bias(), in_scale=a._in_scale(a._real_numel(codes)), in_zp=a._zp(codes),
@@ -407,7 +411,7 @@ class ChainInt8Layer(nn.Module):
             return K.conv2d_i8_chain(oa, nxt, y, relu2=b.relu, **kw)
         if not K.dual_chain_supported(c, sc.c, a.k, b.k, n * h * w):
             out, mid = DualInt8Layer(a, sc if mn is a else mn)(*((x, y) if mn is a else (y, x)))
-            return out, (mid if self.want_codes else None), b(mid)[1]
+            return out, (mid if self.want_codes else None), b(mid)[1]      # (row-major: every reader takes that)
         kw["emit3"] = kw.pop("emit2")
         return K.conv2d_i8_dual_chain(mn.operand(x), sc.operand(y), nxt, relu3=b.relu, **kw)
 
@@ -562,6 +566,54 @@ def _chain_pass(gm, report):
         gm.recompile()
 
 
+def _block_layout_pass(gm, report):
+    """The fp32 block tensor between two chain kernels - written by one, read as the shortcut by the next, by nothing else - goes
+    CHUNK-MAJOR (K.ChunkMajor, DLMCQ_FP32_*_CHUNK_MAJOR): both kernels walk it chunk by chunk, and HBM serves planes in which
+    neighbouring workgroups' pieces are neighbours faster than 256-byte pieces of K * 4-byte rows (chain launches -11 ... -18 % at
+    14^2 / 56^2, tools/chain_ab.py --abcm).  A private layout of the plan: same values.  Instantiations that keep their two fp32 tensors
+    in one layout (K.CHAIN_ONE_LAYOUT) get both or neither."""
+    graph = gm.graph
+    modules = dict(gm.named_modules())
+
+    def chain_of(node):
+        m = modules.get(node.target) if node.op == "call_module" else None
+        return m if isinstance(m, ChainInt8Layer) else None
+    chains = [n for n in graph.nodes if chain_of(n) is not None]
+    out_node, src = {}, {}           # chain node -> the getitem node of its fp32 output; chain node -> the chain node whose output is its shortcut
+    for nc in chains:
+        for u in nc.users:
+            if u.op == "call_function" and u.target is operator.getitem and u.args[1] == 0 and u.users:
+                out_node[nc] = u
+    cm = {}
+    for nc, o in out_node.items():
+        readers = list(o.users)
+        ok = chain_of(nc).a.k % 64 == 0 and all(chain_of(r) is not None and chain_of(r).short is None and len(r.args) == 2 and r.args[1] is o
+                                                 and r.args[0] is not o for r in readers)
+        cm[nc] = ok
+        if ok:
+            for r in readers:
+                src[r] = nc
+    changed = True
+    while changed:                   # one layout per call where the kernel has registers for one set of offsets only
+        changed = False
+        for nc in chains:
+            m = chain_of(nc)
+            if m.short is not None or (m.main.c, m.b.k) not in K.CHAIN_ONE_LAYOUT or nc not in out_node:
+                continue
+            icm, ocm = cm.get(src.get(nc), False), cm.get(nc, False)
+            if icm and not ocm:
+                cm[src[nc]] = False
+                changed = True
+            elif ocm and not icm:
+                cm[nc] = False
+                changed = True
+    count = 0
+    for nc, flag in cm.items():
+        chain_of(nc).out_cm = bool(flag)
+        count += bool(flag)
+    report.chunk_major = count
+
+
 class StemLayer(_PlanLayer):
     """The network's first convolution (<= 4 input channels) of the frozen plan: the image is quantised into a
     zero-point-padded NHWC4 code buffer and convolved on the matrix cores (csrc/conv_stem_i8.hip)."""
@@ -608,13 +660,14 @@ class FusionReport:
     def __init__(self):
         self.layers = self.relu = self.residual = self.emit = self.fp32_outputs = self.stem = self.pooled = self.dual = 0
         self.chained = 0      # block end + next block's 1x1 pairs running as one kernel
+        self.chunk_major = 0  # ... whose fp32 block output is kept chunk-major for the next chain kernel
         self.dwpw = 0         # depthwise 3x3 + pointwise 1x1 units running as one kernel
         self.skipped = []
 
     def __repr__(self):
         return (f"FusionReport(int8 layers={self.layers}, relu fused={self.relu}, residual fused={self.residual}, "
                 f"code-emitting={self.emit}, fp32 outputs kept={self.fp32_outputs}, stem layers={self.stem}, "
-                f"pools on codes={self.pooled}, dual (conv + shortcut conv) kernels={self.dual}, chained pairs={self.chained}, "
+                f"pools on codes={self.pooled}, dual (conv + shortcut conv) kernels={self.dual}, chained pairs={self.chained} (fp32 outputs chunk-major: {self.chunk_major}), "
                 f"depthwise + pointwise units={self.dwpw}, "
                 f"not eligible={self.skipped})")
 
@@ -861,7 +914,7 @@ def _codes_from_blob(mod_name, blob, layer):
     return q.reshape(rec["shape"]).to(torch.int16)
 
 
-def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int4=True, weight_blob=None, dwpw=False):
+def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int4=True, weight_blob=None, dwpw=False, block_layout=True):
     """Return a `torch.fx.GraphModule` executing `model`'s calibrated quantised forward as the fused int8 plan.
     `pack_int4`: weight codes whose range fits 4 bits are stored packed and expanded by one launch per forward (PackedWeights4).
     `weight_blob`: an integer checkpoint (`dlmc.utils.export.export_quantized_state`) of the same model - the plan takes the
@@ -873,7 +926,9 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int
     `dwpw=True` runs every depthwise 3x3 / stride 1 + pointwise 1x1 unit (MobileOne, MobileNet) as ONE launch
     (csrc/conv_dwpw_i8.hip: the code tensor between the two layers stays in LDS; bit-identical).  Off by default: at MobileOne-S1
     W4A8, batch 1024, the unit takes 270 us either way at 28^2 and 14^2 (148 + 123 and 108 + 114 us as two launches) - both halves
-    are bound by their vector arithmetic (~24 instructions per depthwise element), which fusing does not remove."""
+    are bound by their vector arithmetic (~24 instructions per depthwise element), which fusing does not remove.
+    `block_layout=False` keeps every fp32 block tensor row-major (channels_last) instead of chunk-major between two chain kernels
+    (_block_layout_pass; A/B and tests)."""
     if model.training:
         raise RuntimeError("fuse_inference: the plan is for inference - call model.eval() first")
     report = report if report is not None else FusionReport()
@@ -1039,6 +1094,8 @@ def fuse_inference(model, report=None, dry_run=False, chain_pairs=True, pack_int
     gm.recompile()
     if chain_pairs and not dry_run:
         _chain_pass(gm, report)
+        if block_layout:
+            _block_layout_pass(gm, report)
         if dwpw:      # (off by default: measured no faster than the two launches - both halves of a MobileOne unit are bound by their
             #            own vector arithmetic, not by the code tensor between them: LABNOTES round 4)
             _dwpw_pass(gm, report)

@@ -79,6 +79,16 @@ typedef void* dlmcq_stream_t; /* hipStream_t */
  * (element [n][k2][j] = KRSC element [k2][64 n + j]), so that the 64-column chunk the kernel stages per step is one contiguous
  * K2 x 64 byte block (whole cache lines per LDS-DMA instruction instead of 64-byte pieces of K-byte rows).  Same results. */
 #define DLMCQ_W2_CHUNK_MAJOR 0x200
+/* DLMCQ_FP32_IN_CHUNK_MAJOR / DLMCQ_FP32_OUT_CHUNK_MAJOR (OR-able into the LAST quantiser form - `q2_form` / `q3_form` - of the two chain
+ * entry points): the fp32 shortcut the call reads / the fp32 block output it writes, [M][K], is CHUNK-MAJOR: [K / 64][M][64], every
+ * 64-channel chunk a plane of M rows x 256 bytes (K a multiple of 64).  The kernels walk a tile of rows chunk by chunk; with row-major
+ * tensors the chip's workgroups then touch 256-byte pieces K * 4 bytes apart, spread over hundreds of megabytes, and HBM serves that
+ * pattern at 4.6 - 5.8 TB/s where the same loads and stores reach 5.9 - 6.0 on planes in which neighbouring workgroups' pieces are
+ * neighbours (tools/probes/stream_pattern_probe.hip, round 5; the chain launches themselves: -11 ... -18 % at 14^2 and 56^2).  A private
+ * layout between two of these calls: same values, another place in the buffer.  The two tensors of a call may differ in layout, except
+ * for the 128 -> K -> 128 instantiation (DLMCQ_EINVAL).  A call with one fp32 tensor takes either bit for it. */
+#define DLMCQ_FP32_IN_CHUNK_MAJOR 0x2000
+#define DLMCQ_FP32_OUT_CHUNK_MAJOR 0x4000
 /* Two control bits, OR-able into the `q_form` argument of dlmcq_conv2d_i8_nhwc_fused / _asym / _dual and dlmcq_conv2d_dw_i8_nhwc.
  * DLMCQ_FORCE_TILED: the call runs on the generic kernel of its family (conv_i8_mfma_kernel; conv_dw3*_i8_kernel for the
  * depthwise entry point) even where the library's dispatch would hand it to a specialised one (halo-tile 3x3, weight-resident

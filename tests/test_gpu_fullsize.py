@@ -234,6 +234,14 @@ def test_resnet50_batch512_every_plan_node_against_the_oracle():
     print(f"checked {len(recs)} plan nodes x 6 windows; epilogue / kernel kinds seen: {sorted(kinds)}")
 
 
+def _win4(t, n, p0, ph, q0, qw):
+    """Window [1, K, ph, qw] of image n of an fp32 block tensor, channels_last or chunk-major (dlmc ... kernels.ChunkMajor)."""
+    from dlmc.quantization.scalar import kernels as K
+    if isinstance(t, K.ChunkMajor):
+        return t.window(n, p0, p0 + ph, q0, q0 + qw)
+    return t[n:n + 1, :, p0:p0 + ph, q0:q0 + qw]
+
+
 def _check_chain_node(mod, args, out, idx, counts):
     """One chain kernel (block end + next block's first 1x1): its fp32 output / codes against the oracle's convolution(s) +
     shortcut + ReLU, and the second convolution's codes against the oracle's convolution of the FIRST layer's codes (the
@@ -247,7 +255,7 @@ def _check_chain_node(mod, args, out, idx, counts):
         if mod.short is None:
             w_deq, bias, stride, pad = _layer_params(a)
             ref, mag = _conv_window_ref(args[0], a.act.scale.cpu(), a.act.zp.cpu(), w_deq, bias, stride, pad, win)
-            res = args[1][n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu().double()
+            res = _win4(args[1], n, p0, ph, q0, qw).cpu().double()      # (between two chain kernels the block tensor is a K.ChunkMajor)
             ref, mag = ref.float().double() + res, mag + res.abs()
         else:
             xm, xs = (args[1], args[0]) if mod.swapped else (args[0], args[1])
@@ -259,7 +267,7 @@ def _check_chain_node(mod, args, out, idx, counts):
         ref = torch.relu(ref) if a.relu else ref
         got32 = None
         if fp32 is not None:
-            got32 = fp32[n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu()
+            got32 = _win4(fp32, n, p0, ph, q0, qw).cpu()
             _close(got32, ref, mag, what)
         if codes is not None:
             c = _check_codes(codes[n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu(), got32, ref.float(), a.emit, what)

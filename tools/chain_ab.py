@@ -21,6 +21,8 @@ ap.add_argument("--cases", default="d1,s1,s1t,d2,s2,s2t,s3")
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--iters", type=int, default=7)
 ap.add_argument("--rows", type=int, default=0)
+ap.add_argument("--cm", action="store_true", help="the fp32 tensors chunk-major (DLMCQ_FP32_CHUNK_MAJOR; same checksums: same values)")
+ap.add_argument("--abcm", action="store_true", help="time row-major and chunk-major fp32 tensors alternately, launch by launch, in this process")
 ap.add_argument("--noout", action="store_true", help="also time every case without its fp32 / code stores (lab-free ablation)")
 args = ap.parse_args()
 if args.lib:
@@ -60,6 +62,8 @@ def layer(k, c):
 def csum(t):
     if t is None:
         return 0
+    if isinstance(t, K.ChunkMajor):
+        t = t.buf
     return int(t.view(torch.uint8).to(torch.int64).sum().item()) if t.dtype != torch.float32 else int(t.view(torch.int32).to(torch.int64).sum().item())
 
 
@@ -81,21 +85,24 @@ for name in args.cases.split(","):
                for _ in range(nset)]
         sc = dict(layer(k, c2), in_scale=torch.full((1,), 0.03, device=dev), in_zp=None, stride=st2)
 
-        def run(i, wo=want_out, wc=want_codes):
+        def run(i, wo=want_out, wc=want_codes, cm=args.cm):
             return K.conv2d_i8_dual_chain(dict(a, codes=xs[i]), dict(sc, codes=x2s[i]), b, relu=True, emit=emit, want_out=wo, want_codes=wc,
-                                          relu3=True, emit3=emit2, rows_per_tile=args.rows)
+                                          relu3=True, emit3=emit2, rows_per_tile=args.rows, out_chunk_major=cm)
     else:
         ress = [torch.randn(n, k, h, h, generator=g, device=dev).contiguous(memory_format=torch.channels_last) for _ in range(nset)]
+        ress_cm = [K.ChunkMajor.from_nhwc(r) for r in ress] if (args.cm or args.abcm) else None
 
-        def run(i, wo=want_out, wc=want_codes):
-            return K.conv2d_i8_chain(dict(a, codes=xs[i]), b, ress[i], relu=True, emit=emit, want_out=wo, want_codes=wc, relu2=True,
-                                     emit2=emit2, rows_per_tile=args.rows)
+        def run(i, wo=want_out, wc=want_codes, cm=args.cm):
+            return K.conv2d_i8_chain(dict(a, codes=xs[i]), b, (ress_cm if cm else ress)[i], relu=True, emit=emit, want_out=wo, want_codes=wc,
+                                     relu2=True, emit2=emit2, rows_per_tile=args.rows, out_chunk_major=cm)
     got = run(0)
     torch.cuda.synchronize()
     sums = "/".join(f"{csum(t) & 0xffffffff:08x}" for t in got)
     variants = [(f"lab={fl}" if fl else "as built", fl) for fl in labs]
     if args.noout:
         variants.append(("no stores", -1))
+    if args.abcm:
+        variants.append(("chunk-major", -2))
     times = {lbl: [] for lbl, _ in variants}
     for it in range(args.iters):
         for lbl, fl in variants:
@@ -103,7 +110,9 @@ for name in args.cases.split(","):
                 N.lib.dlmcq_x_chain_lab(fl)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            if fl == -1:
+            if fl == -2:
+                run(it % nset, cm=True)
+            elif fl == -1:
                 run(it % nset, False, False)
             else:
                 run(it % nset)
@@ -118,6 +127,9 @@ for name in args.cases.split(","):
         line += f" | {lbl} {t:7.1f} us {nbytes / t / 1e6:5.2f} TB/s ({nbytes / t / 1e6 / 8:.3f})"
         if fl in total:
             total[fl] += t * count
+        if fl == -2:
+            total_cm = globals().get("total_cm", 0.0) + t * count
+            globals()["total_cm"] = total_cm
     total_bytes += nbytes * count
     print(line, flush=True)
     del xs
@@ -126,6 +138,8 @@ for name in args.cases.split(","):
     else:
         del ress
     torch.cuda.empty_cache()
+if args.abcm and set(args.cases.split(",")) == set(CASES):
+    print(f"SUM over the plan's 11 launches, chunk-major fp32 tensors: {total_cm:8.1f} us  {total_bytes / total_cm / 1e6:.2f} TB/s = {total_bytes / total_cm / 1e6 / 8:.3f} of 8 TB/s")
 if set(args.cases.split(",")) == set(CASES):
     for fl in labs:
         print(f"SUM over the plan's 11 launches, {'lab=' + str(fl) if fl else 'as built'}: {total[fl]:8.1f} us  {total_bytes / 1e9:.3f} GB  "

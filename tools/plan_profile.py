@@ -84,7 +84,8 @@ for mod, args, out, s, e in recs:
         macs = m_ * (w1.numel() + w3.numel())
         xm, xs = (args[1], args[0]) if mod.swapped else (args[0], args[1])     # (a swapped dual chain reads its main operand second)
         nb = xm.numel() + w1.numel() + w3.numel() + m_ * w1.shape[0] * (4 * (out[0] is not None) + (out[1] is not None)) + o.numel()
-        what = f"+ fp32 shortcut {tuple(args[1].shape)}"
+        cmaj = lambda t: type(t).__name__ == "ChunkMajor"       # (the block tensor between two chain kernels: kernels.ChunkMajor)
+        what = f"+ fp32 shortcut{'*' if cmaj(args[1]) else ''} {tuple(args[1].shape)}"
         if mod.short is not None:
             w2 = mod.short.layer.weight
             macs += m_ * w2.numel()
@@ -93,7 +94,7 @@ for mod, args, out, s, e in recs:
         else:
             nb += m_ * w1.shape[0] * 4
         print(f"{us:8.1f} us  CHAIN {str(tuple(xm.shape)):20s} x {str(tuple(w1.shape)):18s} {what:42s} -> x {str(tuple(w3.shape)):18s} "
-              f"{'out ' if out[0] is not None else '    '}{'codes ' if out[1] is not None else '      '}{2 * macs / us / 1e6:6.0f} TOP/s {nb / us / 1e3:6.0f} GB/s")
+              f"{('out*' if cmaj(out[0]) else 'out ') if out[0] is not None else '    '}{'codes ' if out[1] is not None else '      '}{2 * macs / us / 1e6:6.0f} TOP/s {nb / us / 1e3:6.0f} GB/s")
         continue
     if isinstance(mod, DualInt8Layer):
         wa, wb = mod.a.layer.weight, mod.b.layer.weight
