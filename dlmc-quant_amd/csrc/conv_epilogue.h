@@ -37,8 +37,9 @@ struct ConvEpi {
 // `q_form` argument of an entry point -> (form, shifted-emission flag); false = invalid
 static inline bool epi_set_form(ConvEpi& ep, int32_t q_form, int32_t q_lo, int32_t q_hi) {
   const bool shifted = (q_form & DLMCQ_EMIT_SHIFT128) != 0;
-  ep.ctl = (uint32_t)q_form & (DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY | DLMCQ_PIPELINED);
-  ep.q_form = q_form & ~(DLMCQ_EMIT_SHIFT128 | DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY | DLMCQ_PIPELINED);
+  constexpr int32_t CTL = DLMCQ_FORCE_TILED | DLMCQ_ROUTE_ONLY | DLMCQ_PIPELINED | DLMCQ_FP32_IN_CHUNK_MAJOR | DLMCQ_FP32_OUT_CHUNK_MAJOR;
+  ep.ctl = (uint32_t)q_form & CTL;
+  ep.q_form = q_form & ~(DLMCQ_EMIT_SHIFT128 | CTL);
   ep.q_xor = shifted ? 0x80808080u : 0u;
   return ep.q_form >= DLMCQ_FORM_EMULATE && ep.q_form <= DLMCQ_FORM_SYMMETRIC && (!shifted || (q_lo >= 0 && q_hi <= 255));
 }

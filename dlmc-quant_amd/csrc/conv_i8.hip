@@ -741,6 +741,11 @@ static int conv_launch(const void* x, const int8_t* w, float* out, const float* 
   const bool special = plan.halo && !(ep.ctl & DLMCQ_FORCE_TILED), route_only = (ep.ctl & DLMCQ_ROUTE_ONLY) != 0;
   float* const mm_req = ep.mm;
   ep.mm = nullptr;                    // (the specialised kernels below do not write partials)
+  // (only the block-end kernel knows the chunk-major form of the fp32 block tensors: a call that carries the bits and would land
+  //  elsewhere is refused, never silently read row-major.  Callers ask first: DLMCQ_ROUTE_ONLY without the bits)
+  if ((ep.ctl & (DLMCQ_FP32_IN_CHUNK_MAJOR | DLMCQ_FP32_OUT_CHUNK_MAJOR)) &&
+      !(special && conv_pwr_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2)))
+    return DLMCQ_EINVAL;
   if (special && conv_pw_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2 != nullptr))
     return route_only ? DLMCQ_ROUTE_PW : conv_pw_launch(xs, w, bias, wsum, in_scale, in_zero_point, w_scale, N, H, W, C, K, shift, ep, st);
   if (special && conv_pwr_applies(N, H, W, C, K, R, S, stride, pad, dilation, ep, out, seg2))

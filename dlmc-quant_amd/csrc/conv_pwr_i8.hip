@@ -36,6 +36,9 @@ struct PwrArgs {
   const float* zp_in;      // null: 0
   const float* residual;   // [M][K] fp32
   float* out;              // [M][K] fp32 (OUTF instantiations)
+  // layout of those two (one layout per call): bytes from row to row / from a 64-channel chunk to the next.  Row-major [M][K]: K * 4, 256.
+  // Chunk-major [K / 64][M][64] (DLMCQ_FP32_*_CHUNK_MAJOR, conv_chain_i8.hip's block tensors): 256, M * 256
+  int f_rowb, f_chunk;
   int M, K, shift, nslice; // nslice = K / 128 column slices; workgroup b: slice (b >> 3) % nslice, group ((b >> 3) / nslice) * 8 + (b & 7)
   int nblk;                // 32-pixel blocks (M is a multiple of 32: the launcher checks)
   // C2 > 0 (a stage's first block): the shortcut is a second 1x1 convolution into the same pixels, reduced first - x2 codes
@@ -135,7 +138,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_pwr_i8_kernel(PwrArgs a,
   const v4i r_x2 = make_rsrc(RES ? nullptr : a.x2, RES ? 0u : (uint32_t)((int64_t)(a.M / (a.P * a.Q)) * a.H2 * a.W2 * C2));
   const uint32_t xorw2 = (!RES && a.shift2) ? 0x80808080u : 0u;
   const v4i r_o = make_rsrc(OUTF ? a.out : nullptr, OUTF ? (uint32_t)((int64_t)a.M * a.K * 4) : 0u);
-  const int so8 = __builtin_amdgcn_readfirstlane(8 * a.K * 4);      // eight fp32 rows further, as a scalar offset
+  const int so8 = __builtin_amdgcn_readfirstlane(8 * a.f_rowb);     // eight fp32 rows further, as a scalar offset
+  const int fchunk = __builtin_amdgcn_readfirstlane(a.f_chunk);
+  // byte offset of pass p's 32 channels from the slice's first: its 64-channel chunk, then the half of it
+  auto poff = [&](int p) { return (p >> 1) * fchunk + (p & 1) * 128; };
 
   i32x4 areg[NA];
   i32x4 areg2[RES ? 1 : NA2];
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_pwr_i8_kernel(PwrArgs a,
     }
   };
   // the shortcut rows of pass `p` of block `blk`: rows 8 it + rsel, bytes 16 q4 .. + 15 of the pass's 128
-  auto fbase = [&](int blk) { return blk < a.nblk ? ((blk * 32 + rsel) * a.K + n0 + 4 * q4) * 4 : BUF_BIG; };
+  auto fbase = [&](int blk) { return blk < a.nblk ? (blk * 32 + rsel) * a.f_rowb + slice * 2 * fchunk + 16 * q4 : BUF_BIG; };
   const int stride = ngroups * NW;
   int blk = group * NW + wave;
   request(blk);
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_pwr_i8_kernel(PwrArgs a,
       // the next pass's shortcut rows (the last pass: pass 0 of the next block)
       if constexpr (RES) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) bload16s(res[nxt][it], (p + 1 < NP ? vb + (p + 1) * 128 : vbn), r_r, it * so8);
+        for (int it = 0; it < 4; ++it) bload16s(res[nxt][it], (p + 1 < NP ? vb + poff(p + 1) : vbn), r_r, it * so8);
       }
       // the dual form: the shortcut convolution of these 32 channels first, dequantised into registers
       f32x2 ex[RES ? 1 : 8];
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_pwr_i8_kernel(PwrArgs a,
         }
         if constexpr (OUTF) {
           v[it] = relu4_nan(v[it]);
-          bstore16s(v[it], vb + p * 128, r_o, it * so8);
+          bstore16s(v[it], vb + poff(p), r_o, it * so8);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the reads are done before the next pass overwrites the stage)
@@ -333,6 +339,8 @@ bool conv_pwr_applies(int64_t N, int64_t H, int64_t W, int64_t C, int64_t K, int
     if (M * C >= (int64_t)BUF_BIG) return false;
   }
   if (K % PWR_BN != 0 || K > 4096) return false;
+  // one layout for the call's fp32 tensors: with both a shortcut and an output the two bits must agree
+  if (ep.residual && out && ((ep.ctl & DLMCQ_FP32_IN_CHUNK_MAJOR) != 0) != ((ep.ctl & DLMCQ_FP32_OUT_CHUNK_MAJOR) != 0)) return false;
   if ((ep.codes && !aligned16(ep.codes)) || (ep.residual && !aligned16(ep.residual)) || (out && !aligned16(out))) return false;
   if (M < 4096 || M % 32 != 0) return false;
   if (M * K * 4 >= (int64_t)BUF_BIG) return false;     // 32-bit buffer offsets
@@ -376,6 +384,9 @@ int conv_pwr_launch(const int8_t* x, const int8_t* w, float* out, const float* b
   a.residual = ep.residual; a.out = out;
   a.M = (int)(N * P * Q); a.K = (int)K; a.shift = shift;
   a.nblk = a.M / 32;
+  const bool fcm = (ep.ctl & (ep.residual ? DLMCQ_FP32_IN_CHUNK_MAJOR : DLMCQ_FP32_OUT_CHUNK_MAJOR)) != 0;
+  a.f_rowb = fcm ? 256 : a.K * 4;
+  a.f_chunk = fcm ? a.M * 256 : 256;
 #ifndef DLMCQ_PWR_NW256
 #define DLMCQ_PWR_NW256 12
 #endif

@@ -426,7 +426,8 @@ class EmitCodes:
 
 
 def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding=0, dilation=1,
-              residual=None, relu=False, emit=None, want_out=True, w_offset=None, force_tiled=False, pipelined=False, observe=False):
+              residual=None, relu=False, emit=None, want_out=True, w_offset=None, force_tiled=False, pipelined=False, observe=False,
+              out_chunk_major=False):
     """Fused int8 conv / linear on the matrix cores.  `codes`: uint8/int8 activation codes, logically
     (N, C, H, W) in channels_last memory, or (N, C) for a linear layer.  Returns fp32 (N, K, P, Q) in
     channels_last memory (or (N, K)).
@@ -439,7 +440,10 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
     the same results bit for bit; tests compare the two on one tensor, tools time them on one box.  `pipelined` (DLMCQ_PIPELINED, opt-in):
     the persistent, software-pipelined halo-tile 3x3 kernel where it applies (same bytes; measured slower than the plain one).
     `observe` (dlmcq_conv2d_i8_nhwc_fused_observed; needs the fp32 output): the launch also leaves the observer partials of its output -
-    `out._dlmcq_mm = (partials, count, version)` when the kernel that ran has the observing epilogue; `minmax_from_partials` reduces them."""
+    `out._dlmcq_mm = (partials, count, version)` when the kernel that ran has the observing epilogue; `minmax_from_partials` reduces them.
+    `residual` may be a ChunkMajor and `out_chunk_major` asks for the fp32 output as one (the block tensors between chain kernels): the
+    block-end kernel (csrc/conv_pwr_i8.hip) takes them so; where the library's dispatch hands the call to another kernel a ChunkMajor
+    residual is converted first (a copy) and the output comes back as an ordinary tensor."""
     N.require_gpu(codes, wq)
     linear = codes.dim() == 2
     if linear:
@@ -481,11 +485,17 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
         out_codes = q_scale = q_zp = None
         lo = hi = form = 0
         g = 0.0
+        icm = isinstance(residual, ChunkMajor)
+        ocm = bool(out_chunk_major) and out is not None and not linear
         if residual is not None:
             if tuple(residual.shape) != ((n, K) if linear else (n, K, P, Q)) or residual.dtype != torch.float32:
                 raise ValueError("conv2d_i8: residual must be fp32 of the output's shape")
+            if icm:
+                residual = residual.buf
             N.require_gpu(residual)
-            if linear:
+            if icm:
+                pass
+            elif linear:
                 residual = residual.contiguous()
             elif not residual.is_contiguous(memory_format=torch.channels_last):
                 residual = residual.contiguous(memory_format=torch.channels_last)
@@ -515,10 +525,23 @@ def conv2d_i8(codes, wq, wsum, bias, in_scale, in_zp, w_scale, stride=1, padding
                 return N.lib.dlmcq_conv2d_i8_nhwc_fused(
                     *args, N.ptr(residual), int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form | extra, g,
                     N.stream_ptr())
+        cm_bits = 0
+        if icm or ocm:
+            # chunk-major block tensors: only where the block-end kernel takes the call, with one layout for its fp32 tensors (the
+            # library's own dispatch answers: DLMCQ_ROUTE_ONLY).  Otherwise: the ordinary layout, the residual converted
+            if (w_offset is None and not (observe and out is not None) and (residual is None or out is None or icm == ocm)
+                    and N.route(call(N.ROUTE_ONLY)) == N.ROUTE_PWR):
+                cm_bits = (N.FP32_IN_CHUNK_MAJOR if icm else 0) | (N.FP32_OUT_CHUNK_MAJOR if ocm else 0)
+            else:
+                if icm:
+                    residual = ChunkMajor(residual, (n, K, P, Q)).to_nhwc()
+                ocm = False
         tag = N.ROUTE_TAG[N.route(call(N.ROUTE_ONLY))] if PROFILE.enabled else "conv_i8"
-        PROFILE.launch(tag, nbytes, lambda: N.check(call()), ops)
+        PROFILE.launch(tag, nbytes, lambda: N.check(call(cm_bits)), ops)
         if observe and out is not None and w_offset is None and count.value > 0:
             out._dlmcq_mm = (partials, int(count.value), out._version)      # (an in-place write to `out` later invalidates it: the version is checked)
+        if ocm:     # (the same memory, read as [K / 64][M][64])
+            out = ChunkMajor(out.permute(0, 2, 3, 1).reshape(K // 64, n * P * Q, 64), (n, K, P, Q))
         return (out, out_codes) if emit is not None else out
     if force_tiled:
         raise ValueError("conv2d_i8: force_tiled needs an epilogue (the plain fp32 entry point always runs the tiled kernel)")
@@ -633,10 +656,10 @@ def conv2d_dwpw_i8(codes, table, dw_asym, dw_bias, dw_relu, in_zp, emit, pw, rel
     return out
 
 
-def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True, force_tiled=False):
+def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True, force_tiled=False, out_chunk_major=False):
     """conv(a) + conv(b) in one kernel (dlmcq_conv2d_i8_nhwc_dual).  `a`, `b`: dicts with codes, wq, wsum, bias,
     in_scale, in_zp, w_scale and optional stride / padding / dilation; both must produce the same output shape.
-    Returns fp32 (N, K, P, Q) channels_last, or `(out, codes)` with `emit` (see conv2d_i8; `force_tiled` as there)."""
+    Returns fp32 (N, K, P, Q) channels_last, or `(out, codes)` with `emit` (see conv2d_i8; `force_tiled`, `out_chunk_major` as there)."""
     def prep(t):
         c = t["codes"]
         N.require_gpu(c, t["wq"])
@@ -688,8 +711,11 @@ def conv2d_i8_dual(a, b, relu=False, emit=None, want_out=True, force_tiled=False
             N.ptr(cb), N.ptr(b["wq"]), N.ptr(bb), N.ptr(b["wsum"]), N.ptr(sib), N.ptr(zpb), N.ptr(wsb), h2, w2, ch2, R2, S2, st2, pd2, dl2,
             uns2, int(bool(relu)), N.ptr(out_codes), N.ptr(q_scale), N.ptr(q_zp), lo, hi, form | extra, g, N.stream_ptr())
     # (the profile tag from the library's own dispatch: conv_pwr = csrc/conv_pwr_i8.hip's dual form, conv_i8 = the tiled dual kernel)
+    ocm = bool(out_chunk_major) and out is not None and N.route(call(N.ROUTE_ONLY)) == N.ROUTE_PWR
     tag = N.ROUTE_TAG[N.route(call(N.ROUTE_ONLY))] if PROFILE.enabled else "conv_i8"
-    PROFILE.launch(tag, nbytes, lambda: N.check(call()), 2 * oe * (ch * R * S + ch2 * R2 * S2))
+    PROFILE.launch(tag, nbytes, lambda: N.check(call(N.FP32_OUT_CHUNK_MAJOR if ocm else 0)), 2 * oe * (ch * R * S + ch2 * R2 * S2))
+    if ocm:         # (the same memory, read as [K / 64][M][64])
+        out = ChunkMajor(out.permute(0, 2, 3, 1).reshape(K_ // 64, n * P * Q, 64), shape_a)
     return (out, out_codes) if emit is not None else out
 
 
@@ -740,6 +766,12 @@ class ChunkMajor:
         n, k, h, w = self.shape
         rows = self.buf.permute(1, 0, 2).reshape(n, h, w, k)
         return rows.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+
+    def dim(self):
+        return 4
+
+    def numel(self):
+        return self.buf.numel()
 
     def window(self, n, p0, p1, q0, q1):
         """[1, K, p1 - p0, q1 - q0] of image n as an ordinary tensor (tests and tools look at windows of full-size tensors)."""

@@ -319,7 +319,8 @@ class Int8Layer(_PlanLayer):
             kw["w_offset"] = self.w_off
         if self.relu or residual is not None or emit is not None or self.w_off is not None:
             res = K.conv2d_i8(codes, self.wq, self.wsum, self._bias(), self._in_scale(numel), self._zp(codes), self.w_scale,
-                              residual=residual, relu=self.relu, emit=emit, want_out=self.want_out, **kw)
+                              residual=residual, relu=self.relu, emit=emit, want_out=self.want_out,
+                              out_chunk_major=getattr(self, "out_cm", False), **kw)
             out, out_codes = res if emit is not None else (res, None)
         else:
             out, out_codes = K.conv2d_i8(codes, self.wq, self.wsum, self._bias(), self._in_scale(numel), self._zp(codes), self.w_scale, **kw), None
@@ -367,7 +368,7 @@ class DualInt8Layer(nn.Module):
         a = self.a
         oa, ob = a.operand(x), self.b.operand(y)
         emit = a._emit_for(oa["codes"].shape[0], a.layer.weight.shape[0], *a._out_hw(oa["codes"]))
-        res = K.conv2d_i8_dual(oa, ob, relu=a.relu, emit=emit, want_out=a.want_out)
+        res = K.conv2d_i8_dual(oa, ob, relu=a.relu, emit=emit, want_out=a.want_out, out_chunk_major=getattr(self, "out_cm", False))
         out, out_codes = res if emit is not None else (res, None)
         return a._finish(out, out_codes)
 
@@ -566,50 +567,78 @@ def _chain_pass(gm, report):
         gm.recompile()
 
 
+def _block_end_like(m):
+    """A plan layer the library's block-end kernel (csrc/conv_pwr_i8.hip) can take: the only kernel besides the chain kernels that
+    knows chunk-major block tensors.  (Whether it DOES take a call is the library's decision per call - K.conv2d_i8 asks and falls
+    back to the ordinary layout.)"""
+    return (type(m) is Int8Layer and _pointwise(m) and m.c in (256, 512) and m.k % 128 == 0 and m.k_pad == m.k and m.c_pad == m.c and m.relu
+            and m.w_off is None and m.pool is None and m.layer.stride[0] == 1 and not m.act.needs_g and
+            (m.emit is None or ((m.emit.lo, m.emit.hi) == (0, 255) and not m.emit.needs_g)))
+
+
 def _block_layout_pass(gm, report):
-    """The fp32 block tensor between two chain kernels - written by one, read as the shortcut by the next, by nothing else - goes
-    CHUNK-MAJOR (K.ChunkMajor, DLMCQ_FP32_*_CHUNK_MAJOR): both kernels walk it chunk by chunk, and HBM serves planes in which
-    neighbouring workgroups' pieces are neighbours faster than 256-byte pieces of K * 4-byte rows (chain launches -11 ... -18 % at
-    14^2 / 56^2, tools/chain_ab.py --abcm).  A private layout of the plan: same values.  Instantiations that keep their two fp32 tensors
-    in one layout (K.CHAIN_ONE_LAYOUT) get both or neither."""
+    """The fp32 block tensor between two kernels that walk it chunk by chunk - written by a chain kernel or the block-end kernel, read
+    as the shortcut by another of them, by nothing else - goes CHUNK-MAJOR (K.ChunkMajor, DLMCQ_FP32_*_CHUNK_MAJOR): HBM serves planes in
+    which neighbouring workgroups' pieces are neighbours faster than 256-byte pieces of K * 4-byte rows (chain launches -11 ... -18 % at
+    14^2 / 56^2, tools/chain_ab.py --abcm).  A private layout of the plan: same values.  Calls that keep their two fp32 tensors in one
+    layout (K.CHAIN_ONE_LAYOUT; the block-end kernel) get both or neither."""
     graph = gm.graph
     modules = dict(gm.named_modules())
 
-    def chain_of(node):
-        m = modules.get(node.target) if node.op == "call_module" else None
-        return m if isinstance(m, ChainInt8Layer) else None
-    chains = [n for n in graph.nodes if chain_of(n) is not None]
-    out_node, src = {}, {}           # chain node -> the getitem node of its fp32 output; chain node -> the chain node whose output is its shortcut
-    for nc in chains:
-        for u in nc.users:
+    def mod(node):
+        return modules.get(node.target) if node.op == "call_module" else None
+
+    def writer(m):      # can write its fp32 output chunk-major
+        if isinstance(m, ChainInt8Layer):
+            return m.a.k % 64 == 0
+        if isinstance(m, DualInt8Layer):     # (the 256-deep addend read row by row, the 512-deep one sampled: conv_pwr_applies)
+            one = lambda t: type(t) is Int8Layer and t.layer.weight.dim() == 4 and tuple(t.layer.weight.shape[2:]) == (1, 1)
+            dense, other = (m.a, m.b) if m.a.c == 256 else (m.b, m.a)
+            return (one(m.a) and one(m.b) and (dense.c, other.c) == (256, 512) and dense.layer.stride[0] == 1 and m.a.relu and m.a.k % 128 == 0
+                    and m.a.k_pad == m.a.k and m.a.w_off is None and m.b.w_off is None and m.a.pool is None and m.a.emit is not None)
+        return isinstance(m, Int8Layer) and _block_end_like(m)
+
+    def reader(node, o):   # reads `o` as its fp32 shortcut, chunk-major if offered
+        m = mod(node)
+        if len(node.args) != 2 or node.args[1] is not o or node.args[0] is o:
+            return False
+        if isinstance(m, ChainInt8Layer):
+            return m.short is None
+        return isinstance(m, Int8Layer) and _block_end_like(m)
+
+    def one_layout(m):
+        if isinstance(m, ChainInt8Layer):
+            return m.short is None and (m.main.c, m.b.k) in K.CHAIN_ONE_LAYOUT
+        return True         # (the block-end kernel)
+    nodes = [n for n in graph.nodes if isinstance(mod(n), (ChainInt8Layer, DualInt8Layer, Int8Layer))]
+    out_node, src, cm = {}, {}, {}     # node -> getitem of its fp32 output; node -> the node whose output is its shortcut; node -> output chunk-major?
+    for nd in nodes:
+        for u in nd.users:
             if u.op == "call_function" and u.target is operator.getitem and u.args[1] == 0 and u.users:
-                out_node[nc] = u
-    cm = {}
-    for nc, o in out_node.items():
-        readers = list(o.users)
-        ok = chain_of(nc).a.k % 64 == 0 and all(chain_of(r) is not None and chain_of(r).short is None and len(r.args) == 2 and r.args[1] is o
-                                                 and r.args[0] is not o for r in readers)
-        cm[nc] = ok
-        if ok:
-            for r in readers:
-                src[r] = nc
+                out_node[nd] = u
+    for nd, o in out_node.items():
+        cm[nd] = writer(mod(nd)) and all(reader(r, o) for r in o.users)
+        if cm[nd]:
+            for r in o.users:
+                src[r] = nd
     changed = True
-    while changed:                   # one layout per call where the kernel has registers for one set of offsets only
+    while changed:                   # one layout per call where the kernel has a single set of offsets
         changed = False
-        for nc in chains:
-            m = chain_of(nc)
-            if m.short is not None or (m.main.c, m.b.k) not in K.CHAIN_ONE_LAYOUT or nc not in out_node:
+        for nd in nodes:
+            m = mod(nd)
+            has_shortcut = len(nd.args) == 2 and not isinstance(m, DualInt8Layer) and not (isinstance(m, ChainInt8Layer) and m.short is not None)
+            if nd not in out_node or not has_shortcut or not one_layout(m):
                 continue
-            icm, ocm = cm.get(src.get(nc), False), cm.get(nc, False)
+            icm, ocm = cm.get(src.get(nd), False), cm.get(nd, False)
             if icm and not ocm:
-                cm[src[nc]] = False
+                cm[src[nd]] = False
                 changed = True
             elif ocm and not icm:
-                cm[nc] = False
+                cm[nd] = False
                 changed = True
     count = 0
-    for nc, flag in cm.items():
-        chain_of(nc).out_cm = bool(flag)
+    for nd, flag in cm.items():
+        mod(nd).out_cm = bool(flag)
         count += bool(flag)
     report.chunk_major = count
 
@@ -660,7 +689,7 @@ class FusionReport:
     def __init__(self):
         self.layers = self.relu = self.residual = self.emit = self.fp32_outputs = self.stem = self.pooled = self.dual = 0
         self.chained = 0      # block end + next block's 1x1 pairs running as one kernel
-        self.chunk_major = 0  # ... whose fp32 block output is kept chunk-major for the next chain kernel
+        self.chunk_major = 0  # fp32 block outputs kept chunk-major between two kernels that walk them chunk by chunk (_block_layout_pass)
         self.dwpw = 0         # depthwise 3x3 + pointwise 1x1 units running as one kernel
         self.skipped = []
 

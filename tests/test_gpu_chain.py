@@ -234,9 +234,11 @@ def test_resnet50_plan_chains_the_block_boundaries_and_stays_bit_identical():
         assert plain.fusion_report.chained == 0 and rep.chained == 11, rep
         pairs = [m for m in chained.modules() if isinstance(m, ChainInt8Layer)]
         assert len(pairs) == 11 and sum(m.want_codes for m in pairs) == 2 and sum(m.short is not None for m in pairs) == 2
-        # the fp32 block tensor between two chain kernels is chunk-major (8 of the 9 outputs: the last 14^2 chain's is read by the
-        # block-end kernel); the plan that keeps them row-major gives the same logits
-        assert rep.chunk_major == 8 and sum(m.out_cm for m in pairs) == 8 and rowmajor.fusion_report.chunk_major == 0
+        # the fp32 block tensors between kernels that walk them chunk by chunk are chunk-major: the 9 outputs of chain kernels (the last
+        # 14^2 chain's is read by the block-end kernel) and stage 3's first block end (the dual block-end kernel, read by the first 14^2
+        # chain); stage 4's stay row-major (its first block end runs on the tiled kernel).  The plan that keeps them all row-major gives
+        # the same logits
+        assert rep.chunk_major == 10 and sum(m.out_cm for m in pairs) == 9 and rowmajor.fusion_report.chunk_major == 0, rep
         y0, y1, y2 = plain(x * 0.8), chained(x * 0.8), rowmajor(x * 0.8)
     assert torch.equal(y0.view(torch.int32), y1.view(torch.int32)) and torch.equal(y2.view(torch.int32), y1.view(torch.int32))
     assert torch.equal(y1.view(torch.int32), want.view(torch.int32))

@@ -208,7 +208,7 @@ def test_resnet50_batch512_every_plan_node_against_the_oracle():
                     xin = O.fq_zeropoint(xin.cpu(), mod.act.scale.cpu(), mod.act.zp.cpu(), mod.act.lo, mod.act.hi)[0].to(torch.uint8)
                 ref, mag = _conv_window_ref(xin, mod.act.scale.cpu(), mod.act.zp.cpu(), w_deq, bias, stride, pad, win)
                 if len(args) > 1:
-                    res = args[1][n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu().double()
+                    res = _win4(args[1], n, p0, ph, q0, qw).cpu().double()
                     mag = mag + res.abs()
                     ref = ref.float().double() + res
                 ref = torch.relu(ref) if mod.relu else ref
@@ -217,7 +217,7 @@ def test_resnet50_batch512_every_plan_node_against_the_oracle():
             ref32 = ref.float()
             got32 = None
             if fp32 is not None:
-                got32 = fp32[n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu()
+                got32 = _win4(fp32, n, p0, ph, q0, qw).cpu()
                 _close(got32, ref, mag, what)
             if codes is not None:
                 c = _check_codes(codes[n:n + 1, :, p0:p0 + ph, q0:q0 + qw].cpu(), got32, ref32, emit, what)

@@ -224,6 +224,14 @@ def test_residual_block_end_kernel_is_the_tiled_kernel_bit_for_bit(case):
     if want_out:
         assert torch.equal(out.view(torch.int32), ow.view(torch.int32)), "fp32 block output differs from the tiled kernel (bitwise, whole tensor)"
     del ow, gw
+    # round 5: the fp32 shortcut (and output) chunk-major - K.ChunkMajor, DLMCQ_FP32_IN / OUT_CHUNK_MAJOR: the same values in [K / 64][M][64] planes
+    (oc, gc), tags = _tagged(K, lambda: K.conv2d_i8(codes, wq, wsum, bias, s_in, in_zp, s_w, residual=K.ChunkMajor.from_nhwc(short), relu=True,
+                                                  emit=emit, want_out=want_out, out_chunk_major=True))
+    assert tags == ["conv_pwr"], tags
+    assert torch.equal(gc, got), "codes differ with a chunk-major shortcut"
+    if want_out:
+        assert isinstance(oc, K.ChunkMajor) and torch.equal(oc.to_nhwc().view(torch.int32), out.view(torch.int32)), "chunk-major fp32 output differs"
+    del oc, gc
     nsub = max(1, 4095 // (h * w))
     cl = lambda t: t.contiguous(memory_format=torch.channels_last)
     for sl in (slice(0, nsub), slice(n - nsub, n)):        # the tiled kernel on the first and on the last images (fewer than 4 096 pixels)
@@ -245,6 +253,33 @@ def test_residual_block_end_kernel_is_the_tiled_kernel_bit_for_bit(case):
         if want_out:
             o = out.permute(0, 2, 3, 1).reshape(m, k).double()
             assert float((o - y).abs()[ok].max()) < 1e-3
+
+
+def test_chunk_major_shortcut_where_the_tiled_kernel_takes_the_call():
+    """A K.ChunkMajor shortcut handed to a call the block-end kernel does not take (fewer than 4 096 pixels): the wrapper converts it, the
+    result is the ordinary call's; the C entry point itself refuses the layout bits there (DLMCQ_EINVAL) instead of reading row-major."""
+    from dlmc import _native as N
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator(device=DEV).manual_seed(9)
+    n, c, k, h = 8, 256, 128, 14
+    codes = torch.randint(0, 256, (n, c, h, h), generator=g, device=DEV, dtype=torch.uint8).contiguous(memory_format=torch.channels_last)
+    wq = torch.randint(-127, 128, (k, 1, 1, c), generator=g, device=DEV, dtype=torch.int8)
+    wsum = wq.to(torch.int32).sum(dim=(1, 2, 3)).to(torch.int32).contiguous()
+    s_w = torch.full((k,), 0.0002, device=DEV)
+    one = torch.full((1,), 0.02, device=DEV)
+    short = torch.randn((n, k, h, h), generator=g, device=DEV).contiguous(memory_format=torch.channels_last)
+    emit = K.EmitCodes(torch.full((1,), 0.05, device=DEV), None, 0, 255, N.FORM_ZEROPOINT)
+    (o0, c0), t0 = _tagged(K, lambda: K.conv2d_i8(codes, wq, wsum, None, one, None, s_w, residual=short, relu=True, emit=emit, want_out=True))
+    (o1, c1), t1 = _tagged(K, lambda: K.conv2d_i8(codes, wq, wsum, None, one, None, s_w, residual=K.ChunkMajor.from_nhwc(short), relu=True, emit=emit,
+                                                want_out=True, out_chunk_major=True))
+    assert t0 == t1 == ["conv_i8"] and isinstance(o1, torch.Tensor)
+    assert torch.equal(o0.view(torch.int32), o1.view(torch.int32)) and torch.equal(c0, c1)
+    out = torch.empty_like(o0)
+    cd = torch.empty_like(c0)
+    rc = N.lib.dlmcq_conv2d_i8_nhwc_fused(N.ptr(codes), N.ptr(wq), N.ptr(out), None, N.ptr(wsum), N.ptr(one), None, N.ptr(s_w), n, h, h, c, k, 1, 1, 1, 0, 1,
+                                          1, N.ptr(short), 1, N.ptr(cd), N.ptr(emit.scale), None, 0, 255, emit.form | N.FP32_IN_CHUNK_MAJOR, 0.0,
+                                          N.stream_ptr())
+    assert rc == -1        # DLMCQ_EINVAL
 
 
 def test_residual_block_end_kernel_declines_what_it_was_not_built_for():
@@ -330,10 +365,18 @@ def test_dual_block_end_kernel_is_the_tiled_kernel_bit_for_bit(case):
     def run(sl):
         d, s_ = dict(dense, codes=cl(xd[sl])), dict(sampled, codes=cl(xs[sl]))
         a, b = (d, s_) if first == "dense" else (s_, d)
-        return K.conv2d_i8_dual(a, b, relu=True, emit=emit, want_out=True)
+        return K.conv2d_i8_dual(a, b, relu=True, emit=emit, want_out=True, out_chunk_major=cmaj)
+    cmaj = False
     (out, got), tags = _tagged(K, lambda: run(slice(0, n)))
     assert tags == ["conv_pwr"], tags
+    cmaj = True            # round 5: the block output chunk-major (K.ChunkMajor): same values
+    (oc, gc), tags = _tagged(K, lambda: run(slice(0, n)))
+    assert tags == ["conv_pwr"] and isinstance(oc, K.ChunkMajor) and torch.equal(gc, got) and torch.equal(oc.to_nhwc().view(torch.int32), out.view(torch.int32))
+    del oc, gc
     nsub = max(1, 4095 // (hw * hw))
+    (osub, csub), tags = _tagged(K, lambda: run(slice(0, nsub)))       # (where the tiled kernel takes the call the output stays an ordinary tensor)
+    assert tags == ["conv_i8"] and isinstance(osub, torch.Tensor)
+    cmaj = False
     for sl in (slice(0, nsub), slice(n - nsub, n)):
         (osub, csub), tags = _tagged(K, lambda: run(sl))
         assert tags == ["conv_i8"], tags
