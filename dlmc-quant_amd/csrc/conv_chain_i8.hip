@@ -380,12 +380,15 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     const int8_t* wb = lds + P * WCH;
     const int8_t* pp = par0 + P * PAR + (wc * 32 + l31) * 4;
     i32x16 acc;
-    float extra[DUALH ? 16 : 1];
-    // (the constant (shift - zp) * SUM qw of a column is what its accumulators START from: one add per element less)
+    // (round 5: the accumulators start from ZERO - the matrix instruction's inline constant, no register moves - and the column's constant
+    //  (shift - zp) * SUM qw joins in fp32: |sum| <= 256 * 128 * 127 and |constant| <= 128 * 256 * 127, so both conversions and their sum are
+    //  exact (< 2^24) and fma(float(sum) + float(constant), m, b) is fma(float(sum + constant), m, b) bit for bit; the chain runs on register
+    //  PAIRS - v_pk_add_f32 / v_pk_fma_f32 -: 2 instructions per element where the integer form had 3)
+    f32x2 extra2[DUALH ? 8 : 1];
     if constexpr (DUALH) {   // the shortcut convolution first: dequantised, it waits in registers for the block's own sum
-      const int corr2 = dz1b * *reinterpret_cast<const int*>(pp + 1024 + 256);
+      const float corr2f = (float)(dz1b * *reinterpret_cast<const int*>(pp + 1024 + 256));
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = corr2;
+      for (int i = 0; i < 16; ++i) acc[i] = 0;
       const int r = wc * 32 + l31;
 #pragma unroll
       for (int s = 0; s < S2; ++s)
@@ -396,13 +399,14 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
         }
       const float mult2 = sin1b * *reinterpret_cast<const float*>(pp + 1024);
       const float bv2 = a.bias2 ? *reinterpret_cast<const float*>(pp + 1024 + 512) : 0.0f;
+      const f32x2 c2{corr2f, corr2f}, m2{mult2, mult2}, b2{bv2, bv2};
 #pragma unroll
-      for (int i = 0; i < 16; ++i) extra[i] = dequant1(acc[i], mult2, bv2);
+      for (int i = 0; i < 8; ++i) extra2[i] = pk_fma(f32x2{(float)acc[2 * i], (float)acc[2 * i + 1]} + c2, m2, b2);
     }
     // ---- GEMM 1: rows wr*32.., columns n*64 + wc*32.. ----
-    const int corr = dz1 * *reinterpret_cast<const int*>(pp + 256);
+    const float corrf = (float)(dz1 * *reinterpret_cast<const int*>(pp + 256));
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = corr;
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
     {
       const int r = wc * 32 + l31;
 #pragma unroll
@@ -421,10 +425,15 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     const float mult = sin1 * *reinterpret_cast<const float*>(pp);
     const float bv = a.bias1 ? *reinterpret_cast<const float*>(pp + 512) : 0.0f;
     float v[16];
+    {
+      const f32x2 c2{corrf, corrf}, m2{mult, mult}, b2{bv, bv};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      v[i] = dequant1(acc[i], mult, bv);
-      if constexpr (DUALH) v[i] = v[i] + extra[DUALH ? i : 0];     // `out += identity`, the identity being a convolution
+      for (int i = 0; i < 8; ++i) {
+        f32x2 f = pk_fma(f32x2{(float)acc[2 * i], (float)acc[2 * i + 1]} + c2, m2, b2);
+        if constexpr (DUALH) f = f + extra2[DUALH ? i : 0];     // `out += identity`, the identity being a convolution
+        v[2 * i] = f.x;
+        v[2 * i + 1] = f.y;
+      }
     }
     // GP groups of 8 rows share ONE tie branch of the quantiser (code4n): with the flags above known at compile time that branch is the
     // only basic-block boundary left in the epilogue, and the scheduler can run a group's LDS round trip under its neighbour's arithmetic
