@@ -37,7 +37,7 @@ __device__ __forceinline__ void bstore16(const f32x4& v, int voff, const v4i& rs
 struct Args {
   const float* in;
   float* out;
-  int M, rowbytes, nchunks, gap, ntiles, cw;   // cw: bytes of a chunk along the row (256, or 512 / 1024 for the wider maps)
+  int M, rowbytes, nchunks, gap, ntiles, cw, mode;   // mode 0: read + write, 1: stores only, 2: loads only   // cw: bytes of a chunk along the row (256, or 512 / 1024 for the wider maps)
 };
 
 // DEPTH chunks in flight; every wave issues 4 loads and 4 stores per chunk of 64 rows x 256 B (maps 0, 1) - or per 64 rows x cw bytes the
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void pattern_kernel(Args a) {
     for (int d = 0; d < DEPTH; ++d)
       if (d < a.nchunks) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bload16<NT>(res[d][g], fo[g] + coff(d), r_in);
+        for (int g = 0; g < 4; ++g) bload16<NT>(res[d][g], a.mode == 1 ? 0x7fff0000 : fo[g] + coff(d), r_in);
       }
     for (int n0 = 0; n0 < a.nchunks; n0 += DEPTH + 1) {
 #pragma unroll
@@ -97,11 +97,11 @@ __global__ __launch_bounds__(256) void pattern_kernel(Args a) {
         for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(res[u][g]));
         if (n + DEPTH < a.nchunks) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) bload16<NT>(res[(u + DEPTH) % (DEPTH + 1)][g], fo[g] + coff(n + DEPTH), r_in);
+          for (int g = 0; g < 4; ++g) bload16<NT>(res[(u + DEPTH) % (DEPTH + 1)][g], a.mode == 1 ? 0x7fff0000 : fo[g] + coff(n + DEPTH), r_in);
         }
         for (int i = 0; i < a.gap; ++i) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bstore16<NT>(res[u][g] + 1.0f, fo[g] + coff(n), r_out);
+        for (int g = 0; g < 4; ++g) bstore16<NT>(res[u][g] + 1.0f, a.mode == 2 ? 0x7fff0000 : fo[g] + coff(n), r_out);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -250,6 +250,22 @@ int main(int argc, char** argv) {
     report("map 5 (chunk-major planes [KD/64][M][64]), depth 1, 2 wg/CU, nt", run<5, 1>(a, 2, true, false, cus));
     report("map 5 (chunk-major planes [KD/64][M][64]), depth 1, 3 wg/CU, nt", run<5, 1>(a, 3, true, false, cus));
     report("map 5, depth 2, 3 wg/CU, nt", run<5, 2>(a, 3, true, false, cus));
+    {
+      auto half = [&](const char* what, float ms) { printf("  %-70s %8.1f us  %5.2f TB/s (one direction)\n", what, ms * 1e3, 1.0 * bytes / ms / 1e9); fflush(stdout); };
+      Args w = a;
+      w.mode = 1;
+      half("STORES ONLY, map 0 (row-major tiles), 3 wg/CU, nt", run<0, 1>(w, 3, true, false, cus));
+      half("STORES ONLY, map 5 (chunk-major planes), 3 wg/CU, nt", run<5, 1>(w, 3, true, false, cus));
+      half("STORES ONLY, map 0, 3 wg/CU, temporal", run<0, 1>(w, 3, false, false, cus));
+      half("STORES ONLY, map 5, 3 wg/CU, temporal", run<5, 1>(w, 3, false, false, cus));
+      w.gap = 32;
+      half("STORES ONLY, map 0, 3 wg/CU, nt, gap 32 x 64 clocks", run<0, 1>(w, 3, true, false, cus));
+      half("STORES ONLY, map 5, 3 wg/CU, nt, gap 32 x 64 clocks", run<5, 1>(w, 3, true, false, cus));
+      w.gap = 0;
+      w.mode = 2;
+      half("LOADS ONLY, map 0, 3 wg/CU, nt", run<0, 1>(w, 3, true, false, cus));
+      half("LOADS ONLY, map 5, 3 wg/CU, nt", run<5, 1>(w, 3, true, false, cus));
+    }
     for (int gap : {32, 64, 96}) {
       Args b = a;
       b.gap = gap;
