@@ -57,7 +57,14 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : DUAL ? (BN == 128 ? 2 : 4) : 
 #define DLMCQ_NB_SWAP128 3
 #endif
   // ring depth: 3 slots (two K steps in flight); A/B hook for the 128-wide A-direct swapped kernel, whose LDS and registers leave room for more
-  constexpr int BM = CV_BM, BK = CV_BK, NBUF = (SWAP && BN == 128 && ADIR && !ASYM) ? DLMCQ_NB_SWAP128 : 3, PF = NBUF - 1;
+#ifndef DLMCQ_NB_DUAL
+#define DLMCQ_NB_DUAL 3
+#endif
+#ifndef DLMCQ_NB_PLAIN
+#define DLMCQ_NB_PLAIN 3
+#endif
+  constexpr int BM = CV_BM, BK = CV_BK,
+                NBUF = (SWAP && BN == 128 && ADIR && !ASYM) ? DLMCQ_NB_SWAP128 : (DUAL ? DLMCQ_NB_DUAL : ((!SWAP && !ASYM) ? DLMCQ_NB_PLAIN : 3)), PF = NBUF - 1;
   // LAB (lab library only): 1 = clock stamps; 2 = no A loads, 3 = no B loads, 4 = no MFMAs, 5 = all lanes load one A address,
   // 6 = swapped epilogue without its arithmetic (the accumulators' low bytes are stored), 7 = no epilogue at all
   // (what-bounds-the-step experiments: results are garbage, only the time means something)
