@@ -134,11 +134,18 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
   const int64_t row0 = (int64_t)blockIdx.x * a.rows_per_tile;
   const int rows_here = (int)((a.M - row0) < a.rows_per_tile ? (a.M - row0) : a.rows_per_tile);
   const int NC = a.KD >> 6;
+#ifndef DLMCQ_CHAIN_ROT
+#define DLMCQ_CHAIN_ROT 0
+#endif
+  // -DDLMCQ_CHAIN_ROT=1 (A/B builds; round 5): workgroup b walks its chunks starting at chunk b mod NC - are all workgroups on the same
+  // quarter of the channels at once?  GEMM 2's integer sum does not care about the order: bit-identical, and +-0 (LABNOTES 16)
+  const int rot = DLMCQ_CHAIN_ROT ? (int)(blockIdx.x % (unsigned)NC) : 0;
+  auto cn = [&](int n) { const int m = n + rot; return m >= NC ? m - NC : m; };
 #ifdef DLMCQ_LAB
   unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + 64 * (size_t)blockIdx.x : nullptr;
   int trn = 0;
 #define CHAIN_STAMP() do { if (tr && trn < 56) tr[trn++] = __builtin_readcyclecounter(); } while (0)
-#define CHAIN_FINE(k) do { if (tr && n == 1) tr[56 + (k)] = __builtin_readcyclecounter(); } while (0)   // chunk 1 in detail (tools/chain_trace.py)
+#define CHAIN_FINE(k) do { if (tr && nseq == 1) tr[56 + (k)] = __builtin_readcyclecounter(); } while (0)   // chunk 1 in detail (tools/chain_trace.py)
 #else
 #define CHAIN_STAMP() do { } while (0)
 #define CHAIN_FINE(k) do { } while (0)
@@ -298,8 +305,9 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
     for (auto& r2 : res)
       for (auto& r : r2) r = f32x4{1.0f, 2.0f, 3.0f, 4.0f};
 #endif
-  auto request = [&](int n, auto par_c) {    // everything chunk n needs from memory
+  auto request = [&](int nseq, auto par_c) {    // everything the nseq-th chunk of this workgroup's walk needs from memory
     constexpr int P = decltype(par_c)::value;
+    const int n = cn(nseq);
     int8_t* wb = lds + P * WCH;
     bool wdma = true;
 #ifdef DLMCQ_LAB
@@ -364,18 +372,19 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
 
   request(0, std::integral_constant<int, 0>{});
 
-  auto chunk = [&](int n, auto par_c) {
+  auto chunk = [&](int nseq, auto par_c) {
     constexpr int P = decltype(par_c)::value;
+    const int n = cn(nseq);
     // chunk n's requests have landed; the stores of chunk n-1 (younger) stay in flight.  Then the barrier: everyone's DMA pieces are
     // visible; everyone left GEMM 2 of chunk n-1.  Wait and barrier are ONE asm statement with a memory clobber, so no LDS access can
     // be scheduled between them or moved across the barrier (a bare __builtin_amdgcn_s_barrier() does not touch memory for the compiler)
-    if (n == 0 || nst == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (nseq == 0 || nst == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     else if (nst == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     else if (nst == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
     CHAIN_STAMP();   // 2 + 3n: chunk n's operands are there
     if constexpr (!DUALH) asm volatile("" : "+v"(res[P][0]), "+v"(res[P][1]), "+v"(res[P][2]), "+v"(res[P][3]));
-    if (n + 1 < NC) request(n + 1, std::integral_constant<int, 1 - P>{});
+    if (nseq + 1 < NC) request(nseq + 1, std::integral_constant<int, 1 - P>{});
 
     const int8_t* wb = lds + P * WCH;
     const int8_t* pp = par0 + P * PAR + (wc * 32 + l31) * 4;
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256, CHAIN_WGS(C1 + C2, KB)) void conv_chain_i8_ker
         }
     }
 #ifdef DLMCQ_LAB
-    if (tr && n == 1) asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[15]));   // (GEMM 1 retired)
+    if (tr && nseq == 1) asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[15]));   // (GEMM 1 retired)
 #endif
     CHAIN_FINE(0);
     // ---- epilogue 1 ----
