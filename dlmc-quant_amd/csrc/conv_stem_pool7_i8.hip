@@ -40,11 +40,27 @@ constexpr int P7_RING = 16 * P7_ROWB;
 constexpr int P7_STG = 2048;        // code tile of one pooled row: 32 pixels x 64 bytes
 constexpr int P7_NEG = -(1 << 30);  // "this convolution pixel does not exist": never wins a maximum (sums stay below 2^23)
 
-template <bool XS>      // XS: uint8 codes, re-centred (^ 0x80) on every fragment read; false: the buffer already holds `code - 128` (or int8 codes)
+// F32IN (lab builds only; round 5, review item 8: "the first layer in ONE launch, measured not estimated"): the kernel reads the fp32
+// image itself - planes [N][C <= 3][H][W], unit pixel stride - and quantises a wave's window rows into its LDS ring (the arithmetic of
+// quantize_pad_nhwc4_x4_kernel: EpiQuant::code4 on channel-planar quads of four pixels, bytes dealt to the pixels by v_perm_b32) instead of
+// receiving them by LDS-DMA from the padded code buffer a separate launch has written.  Pixels outside the image are loaded as 0.0, whose
+// code IS the border code.  Same codes out (tools/stem_fused_lab.py); timing: LABNOTES 16.
+struct Pool7Img {
+  const float* img;
+  int64_t sn, sc, sh;      // element strides of image, channel plane, row
+  int H, W, pad, C;
+  ConvEpi iq;              // the image quantiser (scale, zero point, range, form, DLMCQ_EMIT_SHIFT128)
+};
+
+template <bool XS, bool F32IN = false>      // XS: uint8 codes, re-centred (^ 0x80) on every fragment read; false: the buffer already holds `code - 128` (or int8 codes)
 __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                     const float* __restrict__ bias, const int32_t* __restrict__ wsum,
                                                                     const float* __restrict__ s_in, const float* __restrict__ zp_in,
-                                                                    const float* __restrict__ s_w, Pool7Geom g, int shift, ConvEpi ep) {
+                                                                    const float* __restrict__ s_w, Pool7Geom g, int shift, ConvEpi ep
+#ifdef DLMCQ_LAB
+                                                                    , Pool7Img im
+#endif
+                                                                    ) {
   __shared__ __attribute__((aligned(1024))) int8_t lds[4 * (P7_RING + P7_STG) + 4 * 64 * 4 + 14 * 1024];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
   int8_t* const ring = lds + wave * (P7_RING + P7_STG);
@@ -109,6 +125,51 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
       if (i < 4 * 34) __builtin_amdgcn_global_load_lds((gptr_t)(x + off), (lptr_t)(dst + k * 1024), 16, 0, 0);
     }
   };
+#ifdef DLMCQ_LAB
+  // F32IN: slot i = k * 64 + lane of a group = (row r = i / 36, aligned quad v = i % 36 of image columns 4 (q0 - 2 + v) ..): 36 quads cover the
+  // window's 136 pixels (image columns 4 q0 - 5 ..) whatever its alignment; a quad lies wholly inside or wholly outside the image (W % 4 = 0)
+  f32x4 stq[F32IN ? 3 : 1][F32IN ? 3 : 1];
+  auto load_group = [&](int p) {
+    if constexpr (F32IN) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = k * 64 + lane, r = i / 36, v = i - r * 36;
+        const int h = 4 * p + 5 + r - im.pad, c0 = 4 * (q0 - 2 + v);
+        const bool ok = i < 144 && h >= 0 && h < im.H && c0 >= 0 && c0 < im.W;
+        const float* ptr = im.img + (int64_t)n * im.sn + (int64_t)(ok ? h : 0) * im.sh + (ok ? c0 : 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          stq[F32IN ? k : 0][F32IN ? c : 0] = (ok && c < im.C) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr + c * im.sc)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+    }
+  };
+  auto store_group = [&](int p) {
+    if constexpr (F32IN) {
+      const EpiQuant iq(im.iq);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = k * 64 + lane, r = i / 36, v = i - r * 36;
+        const uint32_t w0 = iq.code4(stq[F32IN ? k : 0][0]);
+        const uint32_t w1 = im.C > 1 ? iq.code4(stq[F32IN ? k : 0][F32IN ? 1 : 0]) : 0u;
+        const uint32_t w2 = im.C > 2 ? iq.code4(stq[F32IN ? k : 0][F32IN ? 2 : 0]) : 0u;
+        // pixel j = bytes j of (w0, w1, w2, 0): quantize_pad_nhwc4_x4_kernel's deal
+        const uint32_t a0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), a1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+        const uint32_t b0 = __builtin_amdgcn_perm(0u, w2, 0x05010400u), b1 = __builtin_amdgcn_perm(0u, w2, 0x07030602u);
+        const uint32_t px[4] = {__builtin_amdgcn_perm(b0, a0, 0x05040100u), __builtin_amdgcn_perm(b0, a0, 0x07060302u),
+                                __builtin_amdgcn_perm(b1, a1, 0x05040100u), __builtin_amdgcn_perm(b1, a1, 0x07060302u)};
+        int8_t* const dst = ring + (((p + 1) & 3) * 4 + r) * P7_ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int off = 4 * v + j - 3;                 // the pixel's place in the 136-pixel window row
+          if (i < 144 && off >= 0 && off < 136) *reinterpret_cast<uint32_t*>(dst + off * 4) = px[j];
+        }
+      }
+    }
+  };
+#else
+  auto load_group = [&](int) {};
+  auto store_group = [&](int) {};
+#endif
   // fragment addresses inside a ring row: O (odd column 2 q - 1): units l31 + hsel; E (even column 2 q): 8 bytes further
   const int fo = (l31 + hsel) * 16;
   auto slot_of = [&](int R) { return ((R - 1) & 15) * P7_ROWB; };
@@ -190,10 +251,19 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
   const bool plainq = epi_plain(ep);                       // unsigned bytes, no zero point: EpiQuant::code4n_plain
 
   // ---- prologue: rows 4 p0 - 3 .. 4 p0 + 8 (three groups), then the upper row of the first window ----
-  issue_group(p0 - 2);
-  issue_group(p0 - 1);
-  issue_group(p0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (F32IN) {
+#pragma unroll 1
+    for (int pp = p0 - 2; pp <= p0; ++pp) {
+      load_group(pp);
+      store_group(pp);
+    }
+    if (p0 + 1 < p1) load_group(p0 + 1);     // (held in registers through the first iteration: a whole iteration between a group's loads and its use)
+  } else {
+    issue_group(p0 - 2);
+    issue_group(p0 - 1);
+    issue_group(p0);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   i32x16 aE[2], aO[2];
   int m[2][16], h[2][16];       // running maximum of the window / the row just convolved, already maximised along x
   if (p0 > 0) {
@@ -212,11 +282,17 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
   for (int p = p0; p < p1; ++p) {
     // group G(p) - this pooled row's new image rows, requested one row ago - has landed; the code stores of the previous
     // row (younger: two instructions, or one when the tile has <= 16 pixels) stay in flight
-    if (p > p0) {
-      if (nvalid > 64) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if constexpr (F32IN) {
+      // the group loaded an iteration ago goes into the ring (rows this iteration does not read), then the next one is requested
+      if (p + 1 < p1) store_group(p + 1);
+      if (p + 2 < p1) load_group(p + 2);
+    } else {
+      if (p > p0) {
+        if (nvalid > 64) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      }
+      if (p + 1 < p1) issue_group(p + 1);
     }
-    if (p + 1 < p1) issue_group(p + 1);
     conv_row(2 * p, aE, aO);
     hmax(h, aE, aO);
 #pragma unroll
@@ -299,11 +375,68 @@ int stem_pool7_launch(const uint8_t* x, const int8_t* w, const float* bias, cons
   g.xtdiv = make_fastdiv((uint32_t)g.xtiles);
   g.bdiv = make_fastdiv((uint32_t)g.bands);
   g.xbytes = N * Hp * Wp * 4;
+#ifdef DLMCQ_LAB
+#define P7_LAB_ARG , Pool7Img{}
+#else
+#define P7_LAB_ARG
+#endif
   if (shift) hipLaunchKernelGGL(conv_stem_pool7_i8_kernel<true>, dim3((uint32_t)((tasks + 3) / 4)), dim3(256), 0, st, x, w, bias, wsum, in_scale,
-                                in_zero_point, w_scale, g, shift, ep);
+                                in_zero_point, w_scale, g, shift, ep P7_LAB_ARG);
   else hipLaunchKernelGGL(conv_stem_pool7_i8_kernel<false>, dim3((uint32_t)((tasks + 3) / 4)), dim3(256), 0, st, x, w, bias, wsum, in_scale,
-                          in_zero_point, w_scale, g, shift, ep);
+                          in_zero_point, w_scale, g, shift, ep P7_LAB_ARG);
   return launch_status();
 }
 
+#ifdef DLMCQ_LAB
+// lab library only: the first layer in ONE launch - image fp32 [N][C][H][W] (strides in elements) -> pooled codes [N][PP][QP][64]
+int stem_pool7_f32_launch(const float* img, int64_t sn, int64_t sc, int64_t sh, int C, int H, int W, int pad, const ConvEpi& iq, const int8_t* w,
+                          const float* bias, const int32_t* wsum, const float* in_scale, const float* in_zero_point, const float* w_scale, int64_t N,
+                          int64_t S, const ConvEpi& ep, hipStream_t st) {
+  const int64_t Hp = H + 2 * pad, Wp = W + 2 * pad;
+  Pool7Geom g;
+  g.N = (int)N; g.Hp = (int)Hp; g.Wp = (int)Wp;
+  g.P = (int)((Hp - 7) / 2 + 1);
+  g.Q = (int)((Wp - S) / 2 + 1);
+  g.PP = g.P / 2;
+  g.QP = g.Q / 2;
+  g.xtiles = (g.QP + 30) / 31;
+  g.rows_per_band = 14;
+  g.bands = (g.PP + g.rows_per_band - 1) / g.rows_per_band;
+  const int64_t tasks = N * g.bands * g.xtiles;
+  if (tasks >= (1ll << 31) || (W & 3) || pad != 3 || C > 3) return DLMCQ_EINVAL;
+  g.ntasks = (uint32_t)tasks;
+  g.xtdiv = make_fastdiv((uint32_t)g.xtiles);
+  g.bdiv = make_fastdiv((uint32_t)g.bands);
+  g.xbytes = 0;
+  Pool7Img im{img, sn, sc, sh, H, W, pad, C, iq};
+  hipLaunchKernelGGL((conv_stem_pool7_i8_kernel<false, true>), dim3((uint32_t)((tasks + 3) / 4)), dim3(256), 0, st, nullptr, w, bias, wsum, in_scale,
+                     in_zero_point, w_scale, g, 0, ep, im);
+  return launch_status();
+}
+#endif
+
 }  // namespace dlmcq
+
+#ifdef DLMCQ_LAB
+// lab library only (tools/stem_fused_lab.py): image quantiser + 7x7 / 2 convolution + ReLU + MaxPool2d(3, 2, 1) + the consumer's quantiser as
+// ONE launch.  `a_*`: the image quantiser (dlmcq_quantize_pad_nhwc4's arguments; DLMCQ_EMIT_SHIFT128 expected for an unsigned range - the
+// kernel multiplies `code - 128`, `in_zero_point` is then `zp - 128`); the rest: dlmcq_conv2d_i8_stem_pool's.
+extern "C" int dlmcq_x_stem_pool7_f32(const float* img, int64_t N, int64_t C, int64_t H, int64_t W, int64_t stride_n, int64_t stride_c,
+                                      int64_t stride_h, int32_t pad, const float* a_scale, const float* a_zero_point, int32_t a_lo, int32_t a_hi,
+                                      int32_t a_form, float a_g, const int8_t* w, const float* bias, const int32_t* wsum, const float* in_scale,
+                                      const float* in_zero_point, const float* w_scale, int64_t S, int32_t relu, void* codes, const float* q_scale,
+                                      const float* q_zero_point, int32_t q_lo, int32_t q_hi, int32_t q_form, float q_ste_g, dlmcq_stream_t stream) {
+  using namespace dlmcq;
+  if (!img || !w || !wsum || !in_scale || !w_scale || !codes || !a_scale || !q_scale || N < 1 || C < 1 || C > 3 || S > 8) return DLMCQ_EINVAL;
+  if (!aligned16(img) || (stride_n & 3) || (stride_c & 3) || (stride_h & 3) || !aligned16(codes) || !aligned16(w)) return DLMCQ_EALIGN;
+  ConvEpi iq{};
+  if (!epi_set_form(iq, a_form, a_lo, a_hi)) return DLMCQ_EINVAL;
+  iq.codes = reinterpret_cast<uint8_t*>(uintptr_t(1));      // (EpiQuant resolves its quantiser only for a non-null `codes`)
+  iq.q_scale = a_scale; iq.q_zp = a_zero_point; iq.q_lo = (float)a_lo; iq.q_hi = (float)a_hi; iq.q_g = a_g;
+  ConvEpi ep{};
+  ep.relu = relu != 0; ep.codes = static_cast<uint8_t*>(codes); ep.q_scale = q_scale; ep.q_zp = q_zero_point;
+  ep.q_lo = (float)q_lo; ep.q_hi = (float)q_hi; ep.q_g = q_ste_g; ep.q_form = q_form;
+  return stem_pool7_f32_launch(img, stride_n, stride_c, stride_h, (int)C, (int)H, (int)W, pad, iq, w, bias, wsum, in_scale, in_zero_point, w_scale, N, S,
+                               ep, reinterpret_cast<hipStream_t>(stream));
+}
+#endif
