@@ -179,13 +179,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
     int wfl = wfo;
     asm volatile("" : "+v"(wfl));       // (the fragments are re-read per row: hoisted out of the loop they would cost 56 registers; an
                                         //  opaque OFFSET, not an opaque pointer - that would lose the LDS address space: flat loads)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        aE[j][i] = 0;
-        aO[j][i] = 0;
-      }
+    // (the sums start from the matrix instruction's inline zero - its C operand in filter row 0 - not from 64 register moves per row)
+    const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // software pipeline of depth one, pinned: the fragments of filter row r + 1 are requested, then the four MFMAs of row r issue
     // (left to itself the scheduler hoists all 35 LDS reads of a row to the top: 140 registers)
     i32x4 o, e, w0, w1;
@@ -205,10 +200,10 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
       __builtin_amdgcn_sched_barrier(0);
       const i32x4 ox = XS ? i32x4{(int)(o.x ^ xorw), (int)(o.y ^ xorw), (int)(o.z ^ xorw), (int)(o.w ^ xorw)} : o;
       const i32x4 ex = XS ? i32x4{(int)(e.x ^ xorw), (int)(e.y ^ xorw), (int)(e.z ^ xorw), (int)(e.w ^ xorw)} : e;
-      aE[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, ex, aE[0], 0, 0, 0);
-      aO[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, ox, aO[0], 0, 0, 0);
-      aE[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, ex, aE[1], 0, 0, 0);
-      aO[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, ox, aO[1], 0, 0, 0);
+      aE[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, ex, r == 0 ? zero16 : aE[0], 0, 0, 0);
+      aO[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, ox, r == 0 ? zero16 : aO[0], 0, 0, 0);
+      aE[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, ex, r == 0 ? zero16 : aE[1], 0, 0, 0);
+      aO[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, ox, r == 0 ? zero16 : aO[1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       o = o2; e = e2; w0 = v0; w1 = v1;
     }
@@ -234,7 +229,9 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int right = __builtin_amdgcn_update_dpp(P7_NEG, aO[j][i], 0x130 /* wave_shl:1: lane q reads lane q + 1 */, 0xf, 0xf, false);
+          // wave_shl:1: lane q reads lane q + 1.  (Lane 63 has no source and reads 0, lane 31 reads the other channel half: both are pooled column
+          // 31 of the tile, which is never stored - so no "never wins" value has to be moved into the destination first: 64 moves per row)
+          const int right = __builtin_amdgcn_mov_dpp(aO[j][i], 0x130, 0xf, 0xf, true);
           h[j][i] = max(max(noleft ? P7_NEG : aO[j][i], aE[j][i]), right);
         }
     } else {
@@ -242,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool7_i8_kernel(const uint8_
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int right = __builtin_amdgcn_update_dpp(P7_NEG, aO[j][i], 0x130, 0xf, 0xf, false);
+          const int right = __builtin_amdgcn_mov_dpp(aO[j][i], 0x130, 0xf, 0xf, true);
           h[j][i] = max(max(aO[j][i], aE[j][i]), right);
         }
     }
