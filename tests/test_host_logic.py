@@ -285,3 +285,26 @@ def test_bench_refuses_counter_tails_that_are_not_the_step_s_launches(tmp_path):
     assert got is None and "TAIL holds (6, 6) dispatches" in why
     got, src, why = bench.pmc_traffic("conv_pwr_i8_kernel", 4, 1, directory=str(tmp_path))
     assert got is None and "no profiles" in why
+
+
+def test_chunk_major_block_tensor_round_trip_on_the_host():
+    """kernels.ChunkMajor (the fp32 block tensor between two chain kernels, DLMCQ_FP32_*_CHUNK_MAJOR): [K / 64][N H W][64] planes of the same
+    values - conversions and windows are plain tensor arithmetic, checked here without a GPU; the kernels' side of it: tests/test_gpu_chain.py."""
+    import torch
+    from dlmc.quantization.scalar import kernels as K
+    g = torch.Generator().manual_seed(4)
+    t = torch.randn(3, 192, 5, 7, generator=g).contiguous(memory_format=torch.channels_last)
+    cm = K.ChunkMajor.from_nhwc(t)
+    assert cm.shape == (3, 192, 5, 7) and tuple(cm.buf.shape) == (3, 3 * 5 * 7, 64) and cm.dim() == 4 and cm.numel() == t.numel()
+    # element (n, k, h, w) sits at plane k // 64, row (n H + h) W + w, column k % 64
+    for n, k, h, w in ((0, 0, 0, 0), (2, 191, 4, 6), (1, 64, 2, 3), (2, 127, 0, 5)):
+        assert cm.buf[k // 64, (n * 5 + h) * 7 + w, k % 64] == t[n, k, h, w]
+    back = cm.to_nhwc()
+    assert torch.equal(back, t) and back.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(cm.window(1, 1, 4, 2, 7), t[1:2, :, 1:4, 2:7])
+    e = K.ChunkMajor.empty(2, 128, 4, 4, "cpu")
+    assert tuple(e.buf.shape) == (2, 32, 64) and e.shape == (2, 128, 4, 4)
+    with pytest.raises(ValueError):
+        K.ChunkMajor.from_nhwc(torch.zeros(1, 96, 2, 2))          # K % 64 != 0
+    with pytest.raises(ValueError):
+        K.ChunkMajor.from_nhwc(torch.zeros(1, 64, 2, 2, dtype=torch.float16))
