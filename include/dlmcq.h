@@ -86,7 +86,10 @@ typedef void* dlmcq_stream_t; /* hipStream_t */
  * pattern at 4.6 - 5.8 TB/s where the same loads and stores reach 5.9 - 6.0 on planes in which neighbouring workgroups' pieces are
  * neighbours (tools/probes/stream_pattern_probe.hip, round 5; the chain launches themselves: -11 ... -18 % at 14^2 and 56^2).  A private
  * layout between two of these calls: same values, another place in the buffer.  The two tensors of a call may differ in layout, except
- * for the 128 -> K -> 128 instantiation (DLMCQ_EINVAL).  A call with one fp32 tensor takes either bit for it. */
+ * for the 128 -> K -> 128 instantiation (DLMCQ_EINVAL).  A call with one fp32 tensor takes either bit for it.
+ * The same two bits in `q_form` of dlmcq_conv2d_i8_nhwc_fused (its `residual` / `out`) and dlmcq_conv2d_i8_nhwc_dual (`out`): honoured where
+ * the block-end kernel takes the call (DLMCQ_ROUTE_PWR - ask with DLMCQ_ROUTE_ONLY, without the bits), one layout per call; anywhere else the
+ * call is refused with DLMCQ_EINVAL rather than run on a kernel that would read or write the tensor row-major. */
 #define DLMCQ_FP32_IN_CHUNK_MAJOR 0x2000
 #define DLMCQ_FP32_OUT_CHUNK_MAJOR 0x4000
 /* Two control bits, OR-able into the `q_form` argument of dlmcq_conv2d_i8_nhwc_fused / _asym / _dual and dlmcq_conv2d_dw_i8_nhwc.
